@@ -1,0 +1,154 @@
+/*
+ * ssq_hip.h -- C-ABI of libssq_hip.so, the MI355X (gfx950) synchrosqueezing engine.
+ *
+ * This header is the drop-in boundary for the hot path of jesusdpa1/ssqueeze_rs:
+ * each entry point replaces one PyO3 `#[pyfunction]` of the reference's `_rs`
+ * extension module (registered at rust/src/lib.rs:22-35).  Plain pointers and
+ * sizes only; no Python, no torch types.  All functions return 0 on success and
+ * a non-zero status on failure; `ssq_last_error()` then holds a message
+ * (thread-local).  The library never frees or retains caller memory.
+ *
+ * dtype: SSQ_F32 (float in, interleaved complex-float out) or SSQ_F64
+ * (double in, interleaved complex-double out).  SSQ_F64 with batch == 1 is the
+ * reference's own configuration (PyReadonlyArray1<f64> in, complex128 out).
+ * Batches are C-contiguous `[batch][N]` in and `[batch][rows][cols]` out.
+ *
+ * Two families:
+ *   *_host  : host pointers in/out (H2D, kernels, D2H inside) -- what the
+ *             Python/NumPy mirror `ssqueeze_rs_amd._rs` binds.
+ *   plans   : device pointers + a caller stream, no allocation and no host
+ *             synchronisation in the exec call (hipGraph-capturable) -- what
+ *             batch pipelines and bench.py bind.
+ */
+#ifndef SSQ_HIP_H
+#define SSQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SSQ_F32 = 0, SSQ_F64 = 1 };
+enum { SSQ_PAD_REFLECT = 0, SSQ_PAD_ZERO = 1 };          /* stft_utils.rs:19-65, utils/array.rs:52-98 */
+enum { SSQ_SQUEEZE_SUM = 0, SSQ_SQUEEZE_LEBESGUE = 1 };  /* ssq_stft.rs:292-296, ssq_cwt.rs:199-206 */
+enum { SSQ_WAVELET_GMW = 0, SSQ_WAVELET_MORLET = 1 };    /* cwt.rs:496-543 */
+enum { SSQ_FREQS_LOG = 0, SSQ_FREQS_LINEAR = 1 };        /* ssq_cwt.rs:56-112 */
+enum { SSQ_MAPRANGE_PEAK = 0, SSQ_MAPRANGE_MAXIMAL = 1 };/* ssq_cwt.rs:450-461 */
+/* what a STFT-family plan writes to its output */
+enum {
+  SSQ_OUT_TX  = 0,   /* synchrosqueezed STFT            (ssq_stft.rs:270-301) */
+  SSQ_OUT_SX  = 1,   /* STFT                            (stft.rs:47-85)       */
+  SSQ_OUT_DSX = 2,   /* derivative STFT                 (ssq_stft.rs:205-211,227) -- test hook */
+  SSQ_OUT_WK  = 3    /* (w, k) per bin as (re, im)      (ssq_stft.rs:11-39,280-289) -- test hook */
+};
+
+/* ---- library / device ----------------------------------------------------- */
+const char* ssq_last_error(void);
+const char* ssq_hello_from_bin(void);                    /* lib.rs:16-19 */
+int ssq_device_count(int* count);
+int ssq_set_device(int device);
+int ssq_device_info(int* cu_count, int64_t* hbm_bytes, char* name, int name_len);
+
+/* ---- shape helpers (so callers can allocate outputs) ---------------------- */
+/* stft.rs:32-34 / ssq_stft.rs:182-184 */
+int ssq_stft_shape(int64_t n_signal, int64_t n_fft, int64_t hop, int64_t* n_freqs, int64_t* n_frames);
+/* utils/array.rs:9-11 with cwt.rs:87,98: P = next_power_of_2(N + N/2), n1 = (P-N)/2 */
+int ssq_cwt_pad_len(int64_t n_signal, int64_t* pad_len, int64_t* n1);
+/* cwt.rs:461-489 / ssq_cwt.rs:300-326; simd_variant selects cwt_simd.rs:474-545.
+ * Call with scales == NULL to obtain *na only. */
+int ssq_log_scales(int64_t n_signal, int64_t nv, int simd_variant, int64_t* na, double* scales);
+/* ssq_stft.rs:104-119: centre zero-pad / centre-crop `window[win_n]` to n_fft */
+int ssq_size_window(const double* window, int64_t win_n, int64_t n_fft, double* out);
+/* ssq_stft.rs:131-179: spectral derivative of the window (Nyquist term kept) */
+int ssq_diff_window(const double* window, int64_t n_fft, double* out);
+/* ssq_cwt.rs:450-469: the `ssq_freqs` vector ssq_cwt returns */
+int ssq_cwt_ssq_freqs(const double* scales, int64_t na, int64_t n_signal, double dt,
+                      int maprange, int freq_dist, double* ssq_freqs);
+
+/* ---- host-pointer entry points (replace the PyO3 functions) ---------------- */
+/* _rs.stft            rust/src/spectral/stft.rs:12-95
+ * window has n_fft entries.  Sx: [batch][n_freqs][n_frames]; freqs: [n_freqs] (cycles/sample). */
+int ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
+                  const double* window, int64_t n_fft, int64_t hop, int padtype,
+                  void* Sx, double* freqs);
+
+/* _rs.ssq_stft        rust/src/spectral/ssq_stft.rs:72-313
+ * `window` is already sized to n_fft (ssq_size_window).  gamma < 0 selects the default
+ * 10*EPS64 (ssq_stft.rs:258-261).  Tx: [batch][n_freqs][n_frames]; ssq_freqs: [n_freqs].
+ * dbg_* may be NULL; when given they receive Sx, dSx (complex) and (w,k) pairs. */
+int ssq_ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
+                      const double* window, int64_t n_fft, int64_t hop, double fs,
+                      int padtype, int squeezing, double gamma,
+                      void* Tx, double* ssq_freqs,
+                      void* dbg_Sx, void* dbg_dSx, void* dbg_wk);
+
+/* _rs.cwt / _rs.cwt_simd   rust/src/spectral/cwt.rs:46-144, cwt_simd.rs:52-150
+ * Wx, dWx: [batch][na][cols], cols = rpadded ? P : N.  dWx may be NULL (derivative=False). */
+int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
+                 int wavelet, const double* scales, int64_t na, double dt,
+                 int l1_norm, int padtype, int rpadded,
+                 void* Wx, void* dWx);
+
+/* _rs.ssq_cwt         rust/src/spectral/ssq_cwt.rs:244-493
+ * Tx: [batch][na][N]; ssq_freqs: [na] (not flipped).  dbg_* may be NULL:
+ * Wx, dWx (unpadded, complex) and (w, k-or--1) pairs. */
+int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
+                     int wavelet, const double* scales, int64_t na, double dt,
+                     int freq_dist, int maprange, int padtype, int squeezing,
+                     int flipud, double gamma,
+                     void* Tx, double* ssq_freqs,
+                     void* dbg_Wx, void* dbg_dWx, void* dbg_wk);
+
+/* ---- plans: device-resident batch pipelines -------------------------------- */
+typedef struct ssq_stft_plan ssq_stft_plan;
+/* One plan = one (dtype, N, n_fft, hop, window, fs, padtype, squeezing, gamma) configuration.
+ * force_generic != 0 selects the unfused any-n_fft kernels (test hook). */
+int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal,
+                         const double* window, int64_t n_fft, int64_t hop, double fs,
+                         int padtype, int squeezing, double gamma, int force_generic);
+int ssq_stft_plan_destroy(ssq_stft_plan* plan);
+/* 1 if the fused LDS-tile kernel serves this plan, 0 if the generic kernels do */
+int ssq_stft_plan_is_fused(const ssq_stft_plan* plan);
+/* bytes of device scratch exec needs for `batch` signals with output kind `out_kind` */
+int64_t ssq_stft_plan_workspace_bytes(const ssq_stft_plan* plan, int64_t batch, int out_kind);
+/* d_x: [batch][N]; d_out: [batch][n_freqs][n_frames] complex; async on `stream` (hipStream_t). */
+int ssq_stft_plan_exec(ssq_stft_plan* plan, int out_kind, const void* d_x, int64_t batch,
+                       void* d_out, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+typedef struct ssq_cwt_plan ssq_cwt_plan;
+int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet,
+                        const double* scales, int64_t na, double dt, int padtype);
+int ssq_cwt_plan_destroy(ssq_cwt_plan* plan);
+int64_t ssq_cwt_plan_workspace_bytes(const ssq_cwt_plan* plan, int64_t batch);
+/* cwt: d_Wx/d_dWx [batch][na][cols]; d_dWx may be NULL */
+int ssq_cwt_plan_exec_cwt(ssq_cwt_plan* plan, const void* d_x, int64_t batch, int l1_norm,
+                          int rpadded, void* d_Wx, void* d_dWx,
+                          void* d_workspace, int64_t workspace_bytes, void* stream);
+/* ssq_cwt: d_Tx [batch][na][N]; d_dbg_* may be NULL */
+int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* plan, const void* d_x, int64_t batch,
+                          int freq_dist, int maprange, int squeezing, int flipud, double gamma,
+                          void* d_Tx, void* d_dbg_Wx, void* d_dbg_dWx, void* d_dbg_wk,
+                          void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- device memory / stream / event plumbing for FFI callers --------------- */
+int ssq_dev_malloc(void** ptr, int64_t bytes);
+int ssq_dev_free(void* ptr);
+int ssq_dev_memset(void* ptr, int value, int64_t bytes, void* stream);
+int ssq_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
+int ssq_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
+int ssq_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
+int ssq_stream_create(void** stream);
+int ssq_stream_destroy(void* stream);
+int ssq_stream_sync(void* stream);     /* NULL = default stream */
+int ssq_device_sync(void);
+int ssq_event_create(void** event);
+int ssq_event_destroy(void* event);
+int ssq_event_record(void* event, void* stream);
+int ssq_event_sync(void* event);
+int ssq_event_elapsed_ms(void* start, void* stop, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSQ_HIP_H */

@@ -1,0 +1,578 @@
+"""CPU oracle for the ssqueeze `_rs` hot path (stft / ssq_stft / cwt / cwt_simd / ssq_cwt).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``ssqueeze_rs_amd/`` may import this
+module: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` use it, and only as the checker.
+
+This is a NumPy (float64 / complex128) restatement of the algorithm of the
+reference Rust crate, function by function, *including its quirks* (SURVEY.md
+appendix).  Every function cites the reference ``file:line`` it follows
+(paths relative to the reference checkout root).
+
+PARITY UNPINNED: the reference cannot be built here (Rust, no toolchain, no
+lockfile) and its own tests assert no numeric values, so
+there is no golden vector from the reference to pin this restatement against.
+What *is* pinned: the output shapes / dtypes the reference scripts state
+(`tests/cwt_test.py:49-60`, `tests/ssq_cwt_test.py:49-57`), and the FFT, which
+is the only third-party arithmetic (crate `rustfft` ^6.2, unnormalised
+forward/inverse DFT) and is restated with ``numpy.fft`` (pocketfft), itself
+cross-checked against a direct O(n^2) DFT in ``tests/test_oracle.py``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+
+EPS64 = 2.2204460492503131e-16
+DEFAULT_GAMMA = 10.0 * EPS64          # ssq_stft.rs:258-261, ssq_cwt.rs:438-441
+TWO_PI_LITERAL = 6.283185307179586    # ssq_stft.rs:32
+
+
+class RustPanic(BaseException):
+    """Stands for a Rust panic (surfaces in Python as pyo3_runtime.PanicException,
+    which derives from BaseException)."""
+
+
+# ----------------------------------------------------------------------------
+# helpers shared by the STFT family   (rust/src/spectral/stft_utils.rs)
+# ----------------------------------------------------------------------------
+def stft_pad(x: np.ndarray, n_fft: int, padtype: str) -> np.ndarray:
+    """stft_utils.rs:19-49 (pad_reflect) / :52-65 (pad_zeros).
+
+    Total pad n_fft-1, left = (n_fft-1)//2, right = the rest.  Mirror indices
+    falling outside [0, n) leave zeros (`if mirror_idx < n`; the right side's
+    `n - 2 - i` wraps in release builds and then fails the same test).
+    Unknown padtype -> reflect (stft.rs:28, ssq_stft.rs:127).
+    """
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    pad = n_fft - 1
+    pl = pad // 2
+    pr = pad - pl
+    p = np.zeros(n + pad, dtype=np.float64)
+    p[pl:pl + n] = x
+    if padtype != "zero":
+        i = np.arange(pl)
+        m = pl - i
+        ok = m < n
+        p[i[ok]] = x[m[ok]]
+        i = np.arange(pr)
+        m = n - 2 - i
+        ok = (m >= 0) & (m < n)
+        p[n + pl + i[ok]] = x[m[ok]]
+    return p
+
+
+def stft_frames(n_padded: int, n_fft: int, hop: int) -> int:
+    """stft.rs:33 / ssq_stft.rs:183 (usize arithmetic; underflow or /0 panics)."""
+    if hop <= 0:
+        raise RustPanic("attempt to divide by zero")
+    if n_padded < n_fft:
+        raise RustPanic("attempt to subtract with overflow")
+    return (n_padded - n_fft) // hop + 1
+
+
+def size_window(window: np.ndarray, n_fft: int) -> np.ndarray:
+    """ssq_stft.rs:104-119: centre zero-pad (left=(n_fft-L)//2) or centre crop."""
+    w = np.asarray(window, dtype=np.float64)
+    L = w.shape[0]
+    if L < n_fft:
+        pl = (n_fft - L) // 2
+        out = np.zeros(n_fft, dtype=np.float64)
+        out[pl:pl + L] = w
+        return out
+    if L > n_fft:
+        s = (L - n_fft) // 2
+        return w[s:s + n_fft].copy()
+    return w.copy()
+
+
+def diff_window(win: np.ndarray) -> np.ndarray:
+    """ssq_stft.rs:131-179: g' = Re(IFFT(FFT(g) * i*xi)) / n with
+    xi_k = 2*pi*k~/n, k~ = k (k <= n/2) else k-n.  The Nyquist term is kept."""
+    n = win.shape[0]
+    freqs = np.zeros(n, dtype=np.float64)
+    k = np.arange(n)
+    freqs[: n // 2 + 1] = k[: n // 2 + 1]
+    freqs[n // 2 + 1:] = k[n // 2 + 1:] - float(n)
+    freqs = freqs * (2.0 * math.pi / float(n))          # :146-148
+    W = np.fft.fft(win.astype(np.complex128))
+    W = (-W.imag * freqs) + 1j * (W.real * freqs)       # :163-167
+    w = np.fft.ifft(W, norm="forward")                  # unnormalised inverse
+    return w.real * (1.0 / float(n))                    # :173-176
+
+
+def rust_linspace(a: float, b: float, n: int) -> np.ndarray:
+    """ndarray::Array1::linspace: a + step*i, step=(b-a)/(n-1) (no endpoint fix-up)."""
+    if n <= 0:
+        return np.zeros(0)
+    step = (b - a) / float(n - 1) if n > 1 else 0.0
+    return a + step * np.arange(n, dtype=np.float64)
+
+
+def _frame_matrix(padded: np.ndarray, n_fft: int, hop: int, n_frames: int) -> np.ndarray:
+    idx = (np.arange(n_frames) * hop)[:, None] + np.arange(n_fft)[None, :]
+    return padded[idx]                                   # [n_frames, n_fft]
+
+
+# ----------------------------------------------------------------------------
+# _rs.stft          (rust/src/spectral/stft.rs:12-95)
+# ----------------------------------------------------------------------------
+def stft(x, n_fft: int, hop_length: int, window, padtype: str):
+    x = np.asarray(x, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    if x.shape[0] == 0:
+        raise RustPanic("empty input")
+    padded = stft_pad(x, n_fft, padtype)                 # :25-29
+    n_frames = stft_frames(padded.shape[0], n_fft, hop_length)   # :32-33
+    n_freqs = n_fft // 2 + 1                             # :34
+    if window.shape[0] != n_fft:
+        # apply_window truncates to the shorter (stft_utils.rs:8) and rustfft then
+        # panics on the buffer/plan length mismatch (stft.rs:67).
+        raise RustPanic("FFT buffer length does not match plan length")
+    fr = _frame_matrix(padded, n_fft, hop_length, n_frames) * window[None, :]   # :58
+    S = np.fft.fft(fr, axis=1)[:, :n_freqs]              # :67-74
+    Sx = np.ascontiguousarray(S.T)                       # [n_freqs, n_frames] :81-85
+    freqs = rust_linspace(0.0, 0.5, n_freqs)             # :40
+    return Sx, freqs
+
+
+# ----------------------------------------------------------------------------
+# _rs.ssq_stft      (rust/src/spectral/ssq_stft.rs)
+# ----------------------------------------------------------------------------
+def phase_stft(Sx, dSx, Sfs, gamma):
+    """ssq_stft.rs:11-39."""
+    a, b = dSx.real, dSx.imag
+    c, d = Sx.real, Sx.imag
+    with np.errstate(all="ignore"):
+        pd = (b * c - a * d) / ((c * c + d * d) * TWO_PI_LITERAL)
+        w = np.abs(Sfs[:, None] - pd)
+        w = np.where(np.hypot(c, d) < gamma, np.inf, w)  # Complex::norm() = hypot
+    return w
+
+
+def stft_ssq_freqs(n_freqs: int, fs: float) -> np.ndarray:
+    """ssq_stft.rs:42-54: (i*0.5*fs)/(n_freqs-1) -- rounds differently from Sfs."""
+    i = np.arange(n_freqs, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        return (i * 0.5 * fs) / (float(n_freqs) - 1.0)
+
+
+def nearest_bin_first_min(w: np.ndarray, freqs: np.ndarray) -> np.ndarray:
+    """ssq_stft.rs:280-289: k = first argmin_idx |w - freqs[idx]| with strict `<`
+    (NaN distance never wins -> k stays 0; +inf never reaches here).
+
+    Exact but O(1) per element: a candidate from w/dw, then the reference's own
+    distance expression on candidates-1..+1 picks the first minimum.  Verified
+    against the brute-force scan in tests (`nearest_bin_bruteforce`)."""
+    n = freqs.shape[0]
+    dw = freqs[1] - freqs[0]
+    with np.errstate(all="ignore"):
+        est = np.where(np.isfinite(w), w / dw, 0.0)
+    est = np.clip(np.nan_to_num(est, nan=0.0), 0, n - 1)
+    c = np.rint(est).astype(np.int64)
+    best_k = np.zeros(w.shape, dtype=np.int64)
+    best_d = np.full(w.shape, np.inf)
+    # scan candidates in ascending index so that ties keep the lower index
+    for off in (-2, -1, 0, 1, 2):
+        kk = np.clip(c + off, 0, n - 1)
+        with np.errstate(all="ignore"):
+            dist = np.abs(w - freqs[kk])
+        better = dist < best_d
+        # a candidate equal to an earlier (lower or same) index must not win on ties:
+        best_k = np.where(better, kk, best_k)
+        best_d = np.where(better, dist, best_d)
+    best_k = np.where(np.isnan(w), 0, best_k)
+    # Beyond the last bin fl(w - f_k) can round to the same value for several k
+    # (huge w): the scan's strict `<` then keeps the *first* such k.  Resolve those
+    # by the literal scan, chunked.
+    far = np.isfinite(w) & (w > freqs[n - 1])
+    if far.any():
+        wf = w[far]
+        out = np.empty(wf.shape[0], dtype=np.int64)
+        step = max(1, (1 << 22) // n)
+        for s in range(0, wf.shape[0], step):
+            d = np.abs(wf[s:s + step, None] - freqs[None, :])
+            out[s:s + step] = np.argmin(d, axis=1)       # first occurrence of the min
+        best_k[far] = out
+    return best_k
+
+
+def nearest_bin_bruteforce(w: np.ndarray, freqs: np.ndarray) -> np.ndarray:
+    """Literal restatement of the scan at ssq_stft.rs:280-289 (small inputs only)."""
+    flat = w.reshape(-1)
+    out = np.zeros(flat.shape[0], dtype=np.int64)
+    for t, wv in enumerate(flat):
+        k = 0
+        min_dist = math.inf
+        for idx, f in enumerate(freqs):
+            dist = abs(wv - f)
+            if dist < min_dist:
+                min_dist = dist
+                k = idx
+        out[t] = k
+    return out.reshape(w.shape)
+
+
+def ssq_stft(x, window, n_fft: Optional[int] = None, win_len: Optional[int] = None,
+             hop_len: int = 1, fs: float = 1.0, padtype: str = "reflect",
+             squeezing: str = "sum", gamma: Optional[float] = None,
+             return_intermediates: bool = False):
+    """ssq_stft.rs:72-313."""
+    x = np.asarray(x, dtype=np.float64)
+    window = np.asarray(window, dtype=np.float64)
+    n = x.shape[0]
+    n_fft = min(n, 512) if n_fft is None else int(n_fft)                 # :92
+    win_len = window.shape[0] if win_len is None else int(win_len)       # :93
+    if win_len > n_fft:                                                  # :96-101
+        raise ValueError(
+            f"Window length {win_len} cannot be greater than n_fft {n_fft}")
+    if n == 0 or n_fft == 0:
+        raise RustPanic("empty input")
+    win = size_window(window, n_fft)                                     # :104-119
+    padded = stft_pad(x, n_fft, padtype)                                 # :124-128
+    dwin = diff_window(win)                                              # :131-179
+    n_frames = stft_frames(padded.shape[0], n_fft, hop_len)              # :182-183
+    n_freqs = n_fft // 2 + 1                                             # :184
+    if n_freqs < 2:
+        raise RustPanic("index out of bounds: ssq_freqs[1]")             # :273
+    fr = _frame_matrix(padded, n_fft, hop_len, n_frames)
+    Sx = np.ascontiguousarray(np.fft.fft(fr * win[None, :], axis=1)[:, :n_freqs].T)       # :202,226
+    dSx = np.ascontiguousarray(
+        np.fft.fft((fr * dwin[None, :]) * fs, axis=1)[:, :n_freqs].T)                     # :208,227
+    Sfs = rust_linspace(0.0, 0.5 * fs, n_freqs)                          # :255
+    g = DEFAULT_GAMMA if gamma is None else float(gamma)                 # :258-261
+    w = phase_stft(Sx, dSx, Sfs, g)                                      # :264
+    ssq_freqs = stft_ssq_freqs(n_freqs, fs)                              # :267
+    dw = ssq_freqs[1] - ssq_freqs[0]                                     # :273
+    k = nearest_bin_first_min(w, ssq_freqs)                              # :280-289
+    Tx = np.zeros((n_freqs, n_frames), dtype=np.complex128)
+    cols = np.arange(n_frames)
+    lebesgue = squeezing == "lebesgue"
+    for i in range(n_freqs):                                             # rows ascending = reference order
+        m = ~np.isinf(w[i])                                              # :278
+        if not m.any():
+            continue
+        if lebesgue:
+            wt = np.full(n_frames, 1.0 / float(n_freqs), dtype=np.complex128)   # :294
+        else:
+            wt = Sx[i]                                                   # :293,:295
+        contrib = (wt.real * dw) + 1j * (wt.imag * dw)                   # Complex*f64
+        Tx[k[i, m], cols[m]] += contrib[m]                               # :298
+    if return_intermediates:
+        return Tx, ssq_freqs, dict(Sx=Sx, dSx=dSx, w=w, k=k, Sfs=Sfs, dw=dw, window=win,
+                                   diff_window=dwin)
+    return Tx, ssq_freqs
+
+
+# ----------------------------------------------------------------------------
+# CWT family helpers
+# ----------------------------------------------------------------------------
+def next_power_of_2(n: int) -> int:
+    """utils/array.rs:9-11: 1 << ceil(log2(n)) (f64 log2; n=0 -> -inf -> cast 0 -> 1)."""
+    if n <= 0:
+        return 1
+    return 1 << int(math.ceil(math.log2(float(n))))
+
+
+def cwt_pad(x: np.ndarray, pad_len: int, padtype: str) -> np.ndarray:
+    """utils/array.rs:52-82 (pad_reflect) / :85-98 (pad_zero)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    if pad_len < n:
+        raise RustPanic("attempt to subtract with overflow")
+    pad = pad_len - n
+    pl = pad // 2
+    pr = pad - pl
+    p = np.zeros(pad_len, dtype=np.float64)
+    p[pl:pl + n] = x
+    if padtype != "zero":
+        i = np.arange(pl)
+        m = pl - i
+        ok = m < n
+        p[i[ok]] = x[m[ok]]
+        i = np.arange(pr)
+        m = n - 2 - i
+        ok = (m >= 0) & (m < n)
+        p[n + pl + i[ok]] = x[m[ok]]
+    return p
+
+
+def xifn(scale: float, n: int) -> np.ndarray:
+    """wavelets/base.rs:18-33."""
+    h = scale * (2.0 * math.pi) / float(n)
+    xi = np.zeros(n, dtype=np.float64)
+    i = np.arange(n)
+    xi[: n // 2 + 1] = i[: n // 2 + 1].astype(np.float64) * h
+    xi[n // 2 + 1:] = (i[n // 2 + 1:] - n).astype(np.float64) * h
+    return xi
+
+
+def wavelet_fourier(xi: np.ndarray, scale: float, wavelet: str) -> np.ndarray:
+    """cwt.rs:492-547 (dup cwt_simd.rs:548-613).  Real-valued (imag = 0)."""
+    w = scale * xi
+    psih = np.zeros(xi.shape[0], dtype=np.float64)
+    if wavelet == "morlet":
+        mu = 6.0
+        norm = math.pow(math.pi, -0.25) * math.sqrt(2.0)     # :501 (SQRT_2 constant)
+        k_exp = math.exp(-0.5 * mu * mu)                     # :502
+        m = w >= 0.0                                         # :512
+        wm = w[m]
+        t1 = np.exp(-0.5 * ((wm - mu) * (wm - mu)))          # :515 powi(2)
+        t2 = k_exp * np.exp(-0.5 * (wm * wm))                # :516
+        psih[m] = norm * (t1 - t2)                           # :518
+    else:                                                    # "gmw" | _  :522
+        gamma, beta = 3.0, 60.0
+        m = w > 0.0                                          # :536
+        wm = w[m]
+        with np.errstate(all="ignore"):
+            term = np.exp(beta * np.log(wm) - np.power(wm, gamma))   # :538-539
+        psih[m] = 2.0 * term                                 # :540
+    return psih
+
+
+def log_scales(N: int, nv: int, simd_variant: bool = False) -> np.ndarray:
+    """cwt.rs:461-489 / ssq_cwt.rs:300-326; cwt_simd.rs:474-545 uses exp(p*ln2)
+    instead of 2^p when there are >= 16 scales."""
+    log_min = math.log2(2.0)
+    log_max = math.log2(float(N) * 0.5) if N > 0 else -math.inf
+    num_octaves = log_max - log_min
+    v = math.ceil(num_octaves * float(nv))
+    num = int(v) if (math.isfinite(v) and v > 0) else 0      # `as usize` saturates
+    sf = (log_max - log_min) / float(num - 1) if num > 1 else 0.0
+    out = np.zeros(num, dtype=np.float64)
+    for i in range(num):
+        p = log_min + float(i) * sf
+        if simd_variant and num >= 16:
+            out[i] = math.exp(p * math.log(2.0))
+        else:
+            out[i] = math.pow(2.0, p)
+    return out
+
+
+def _dt_from(fs, t) -> float:
+    """cwt.rs:66-76 / ssq_cwt.rs:283-293."""
+    if t is not None:
+        t = np.asarray(t, dtype=np.float64)
+        if t.shape[0] < 2:
+            raise ValueError("Time vector must have at least 2 elements")
+        return float(t[1] - t[0])
+    if fs is not None:
+        return 1.0 / float(fs)
+    return 1.0
+
+
+def _cwt_core(x, scales, wavelet, dt, padtype, want_d: bool):
+    """Shared by cwt.rs:85-105,169-326 and ssq_cwt.rs:329-431: returns padded
+    (Wx, dWx|None) already multiplied by 1/P, plus (P, n1)."""
+    N = x.shape[0]
+    P = next_power_of_2(N + N // 2)                          # cwt.rs:87
+    padded = cwt_pad(x, P, padtype)                          # :88-92
+    xh = np.fft.fft(padded.astype(np.complex128))            # :147-162
+    n1 = (P - N) // 2                                        # :98
+    xi = xifn(1.0, P)                                        # :189
+    na = scales.shape[0]
+    Wx = np.zeros((na, P), dtype=np.complex128)
+    dWx = np.zeros((na, P), dtype=np.complex128) if want_d else None
+    norm = 1.0 / float(P)                                    # :251
+    for i in range(na):
+        psih = wavelet_fourier(xi, float(scales[i]), wavelet)
+        r = np.fft.ifft(xh * psih, norm="forward")           # unnormalised inverse
+        Wx[i] = (r.real * norm) + 1j * (r.imag * norm)
+        if want_d:
+            dpsih = (psih + 0j) * (1j * (xi / dt))           # :205-208 Complex*Complex(0, w/dt)
+            r = np.fft.ifft(xh * dpsih, norm="forward")
+            dWx[i] = (r.real * norm) + 1j * (r.imag * norm)
+    return Wx, dWx, P, n1
+
+
+def cwt(x, wavelet: str = "gmw", scales=None, fs=None, t=None, nv: int = 32,
+        l1_norm: bool = True, derivative: bool = False, padtype: str = "reflect",
+        rpadded: bool = False, vectorized: bool = True, patience: int = 0,
+        _simd_variant: bool = False):
+    """cwt.rs:46-144 (always a 3-tuple (Wx, scales, dWx|None))."""
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[0]
+    dt = _dt_from(fs, t)
+    if scales is None:
+        scales_a = log_scales(N, nv, simd_variant=_simd_variant)         # :79-82
+    else:
+        scales_a = np.asarray(scales, dtype=np.float64).copy()
+    Wx, dWx, P, n1 = _cwt_core(x, scales_a, wavelet, dt, padtype, derivative)
+    if not l1_norm:                                                      # :253-262
+        sf = np.sqrt(scales_a)[:, None]
+        Wx = (Wx.real * sf) + 1j * (Wx.imag * sf)
+        if dWx is not None:
+            dWx = (dWx.real * sf) + 1j * (dWx.imag * sf)
+    if not rpadded:                                                      # :108-129
+        Wx = np.ascontiguousarray(Wx[:, n1:n1 + N])
+        if dWx is not None:
+            dWx = np.ascontiguousarray(dWx[:, n1:n1 + N])
+    return Wx, scales_a, dWx
+
+
+def cwt_simd(*args, **kw):
+    """cwt_simd.rs:52-150: same numbers as `cwt` except automatic scale generation."""
+    return cwt(*args, _simd_variant=True, **kw)
+
+
+def phase_cwt(Wx, dWx, gamma):
+    """ssq_cwt.rs:15-47."""
+    a, b = dWx.real, dWx.imag
+    c, d = Wx.real, Wx.imag
+    with np.errstate(all="ignore"):
+        pd = (b * c - a * d) / ((c * c + d * d) * 2.0 * math.pi)
+        w = np.abs(pd)
+        w = np.where(np.hypot(c, d) < gamma, np.inf, w)
+    return w
+
+
+def cwt_ssq_freqs(n: int, fmin: float, fmax: float, dist: str) -> np.ndarray:
+    """ssq_cwt.rs:50-113 ("linear" or log2-spaced; unknown -> log)."""
+    out = np.zeros(n, dtype=np.float64)
+    if dist == "linear":
+        step = (fmax - fmin) / float(n - 1) if n > 1 else 0.0
+        for i in range(n):
+            out[i] = fmin + float(i) * step
+    else:
+        lmin, lmax = math.log2(fmin), math.log2(fmax)
+        sf = (lmax - lmin) / float(n - 1) if n > 1 else 0.0
+        for i in range(n):
+            out[i] = math.pow(2.0, lmin + float(i) * sf)
+    return out
+
+
+def rust_round(v: np.ndarray) -> np.ndarray:
+    """f64::round: half away from zero (exact; no +0.5 trick)."""
+    r = np.trunc(v)
+    with np.errstate(invalid="ignore"):
+        adj = np.where(np.abs(v - r) >= 0.5, np.sign(v), 0.0)
+    return r + adj
+
+
+def cwt_bins(w: np.ndarray, ssq_freqs: np.ndarray):
+    """ssq_cwt.rs:135-196: returns (bin, valid); `as isize` saturates, NaN -> 0."""
+    n = ssq_freqs.shape[0]
+    is_log = bool(n > 1 and (ssq_freqs[1] / ssq_freqs[0] > 1.1))          # :135-139
+    with np.errstate(all="ignore"):
+        if is_log:
+            lmin = math.log2(ssq_freqs[0])
+            lstep = (math.log2(ssq_freqs[n - 1]) - lmin) / float(n - 1) if n > 1 else 1.0
+            v = (np.log2(w) - lmin) / lstep                               # :175-176
+        else:
+            lin_min = float(ssq_freqs[0])
+            lstep = (float(ssq_freqs[n - 1]) - lin_min) / float(n - 1) if n > 1 else 1.0
+            v = (w - lin_min) / lstep                                     # :187
+        r = rust_round(v)
+    skip = np.isinf(w) | np.isnan(w)                                      # :167
+    r = np.where(np.isnan(r), 0.0, r)                                     # NaN as isize = 0
+    r = np.clip(r, -9.0e18, 9.0e18)                                       # saturating cast
+    b = r.astype(np.int64)
+    valid = (~skip) & (b >= 0) & (b < n)                                  # :177,:188
+    return b, valid, is_log
+
+
+def ssq_cwt(x, wavelet: str = "gmw", scales=None, fs=None, t=None,
+            ssq_freqs: Optional[str] = None, nv: int = 32, padtype: str = "reflect",
+            squeezing: str = "sum", maprange: str = "peak", difftype: str = "trig",
+            gamma: Optional[float] = None, vectorized: bool = True, flipud: bool = True,
+            return_intermediates: bool = False):
+    """ssq_cwt.rs:244-493."""
+    x = np.asarray(x, dtype=np.float64)
+    N = x.shape[0]
+    dt = _dt_from(fs, t)
+    if scales is None:
+        scales_a = log_scales(N, nv)                                      # :300-326
+    else:
+        scales_a = np.asarray(scales, dtype=np.float64).copy()
+    na = scales_a.shape[0]
+    if na == 0:
+        raise RustPanic("index out of bounds: scales[len-1]")             # :459
+    Wxp, dWxp, P, n1 = _cwt_core(x, scales_a, wavelet, dt, padtype, True)  # :329-431
+    Wx = np.ascontiguousarray(Wxp[:, n1:n1 + N])                          # :434-435
+    dWx = np.ascontiguousarray(dWxp[:, n1:n1 + N])
+    g = DEFAULT_GAMMA if gamma is None else float(gamma)
+    w = phase_cwt(Wx, dWx, g)                                             # :444
+    dist = "log" if ssq_freqs is None else ssq_freqs                      # :447
+    with np.errstate(all="ignore"):
+        if maprange == "maximal":                                         # :450-455
+            dT = float(N) * dt
+            fmin, fmax = 1.0 / dT, 0.5 / dt
+        else:                                                             # :456-460
+            fmin, fmax = 1.0 / float(scales_a[-1]), 1.0 / float(scales_a[0])
+    freqs = cwt_ssq_freqs(na, fmin, fmax, dist)                           # :464-469
+    b, valid, is_log = cwt_bins(w, freqs)
+    kk = (na - 1 - b) if flipud else b                                    # :180-184
+    Tx = np.zeros((na, N), dtype=np.complex128)
+    cols = np.arange(N)
+    lebesgue = squeezing == "lebesgue"
+    for i in range(na):                                                   # scales ascending = reference order
+        m = valid[i]
+        if not m.any():
+            continue
+        if lebesgue:
+            Tx[kk[i, m], cols[m]] += 1.0 / float(na)                      # :201-204
+        else:
+            Tx[kk[i, m], cols[m]] += Wx[i, m]                             # :200,:205,:208
+    if return_intermediates:
+        return Tx, freqs, dict(Wx=Wx, dWx=dWx, w=w, bin=b, valid=valid, k=kk,
+                               is_log=is_log, scales=scales_a, P=P, n1=n1)
+    return Tx, freqs
+
+
+def hello_from_bin() -> str:
+    """lib.rs:16-19."""
+    return "Hello from ssqueeze!"
+
+
+# ----------------------------------------------------------------------------
+# synthetic workloads -- shared by tests and bench
+# ----------------------------------------------------------------------------
+def synth_signal(N: int, b: int = 0, dtype=np.float64) -> np.ndarray:
+    """Signal b of a batch: 3 sines + linear chirp + 1e-3 white noise, seed 1234+b."""
+    rng = np.random.default_rng(1234 + b)
+    n = np.arange(N, dtype=np.float64)
+    x = np.zeros(N, dtype=np.float64)
+    for _ in range(3):
+        f = rng.uniform(0.01, 0.45)
+        A = rng.uniform(0.5, 1.0)
+        ph = rng.uniform(0.0, 2.0 * math.pi)
+        x += A * np.sin(2.0 * math.pi * f * n + ph)
+    f0, f1 = sorted(rng.uniform(0.01, 0.45, size=2))
+    Ac = rng.uniform(0.5, 1.0)
+    x += Ac * np.sin(2.0 * math.pi * (f0 * n + 0.5 * (f1 - f0) / N * n * n))
+    x += 1e-3 * rng.standard_normal(N)
+    return x.astype(dtype)
+
+
+# ----------------------------------------------------------------------------
+# fp32-mode semantics of the HIP kernels (an extension: the reference is fp64 only)
+# ----------------------------------------------------------------------------
+def stft_bins_f32_model(w32: np.ndarray, dw: float, n_freqs: int) -> np.ndarray:
+    """Bin index the fp32 kernels define for a given fp32 `w` (stft_kernels.h phase_bin):
+    u = fma(w, fl32(1/dw), -0.5); k = ceil(u) clamped to [0, n_freqs-1]; NaN -> 0.
+    Exact half-bin ties go to the lower bin, like the reference scan's strict `<`."""
+    w32 = np.asarray(w32, dtype=np.float32)
+    inv = np.float32(1.0 / dw)
+    with np.errstate(all="ignore"):
+        u = (w32.astype(np.float64) * np.float64(inv) - 0.5).astype(np.float32)   # one rounding = fma
+        k = np.where(u >= np.float32(n_freqs - 1), n_freqs - 1, np.ceil(u))
+    k = np.where(np.isnan(w32), 0, k)
+    return np.nan_to_num(k, nan=0.0, posinf=n_freqs - 1).astype(np.int64)
+
+
+def accumulate_tx(Sx: np.ndarray, k: np.ndarray, keep: np.ndarray, dw: float, n_out: int,
+                  lebesgue: bool = False) -> np.ndarray:
+    """Tx[k[i,j], j] += Sx[i,j]*dw over kept bins, rows ascending (ssq_stft.rs:276-301)."""
+    n_rows, n_cols = Sx.shape
+    Tx = np.zeros((n_out, n_cols), dtype=np.complex128)
+    cols = np.arange(n_cols)
+    for i in range(n_rows):
+        m = keep[i]
+        if not m.any():
+            continue
+        wt = np.full(n_cols, 1.0 / float(n_rows), dtype=np.complex128) if lebesgue else Sx[i].astype(np.complex128)
+        Tx[k[i, m], cols[m]] += (wt.real[m] * dw) + 1j * (wt.imag[m] * dw)
+    return Tx

@@ -1,0 +1,71 @@
+"""Build libssq_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`python -m ssqueeze_rs_amd.build` or `build_lib()`.  hipcc cross-compiles without a GPU.
+The built .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libssq_hip.so")
+OBJ_DIR = os.path.join(CSRC, "build")
+ARCH = "gfx950"
+
+SOURCES = ["api_common.hip", "api_stft.hip", "stft_fused.hip", "stft_generic.hip",
+           "api_cwt.hip", "cwt_kernels.hip"]
+CXXFLAGS = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+            "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libssq_hip.so cannot be built")
+
+
+def _newer(src_list, target) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build_lib(force: bool = False, verbose: bool = True) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "ssq_hip.h"))
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer([s] + headers, o):
+            jobs.append([hipcc, *CXXFLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _newer(objs, LIB):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

@@ -1,0 +1,431 @@
+// api_cwt.hip -- CWT-family plans and host entry points of the C-ABI (include/ssq_hip.h).
+// Replaces the PyO3 functions `cwt` / `cwt_simd` (rust/src/spectral/cwt.rs:46-144,
+// cwt_simd.rs:52-150) and `ssq_cwt` (rust/src/spectral/ssq_cwt.rs:244-493).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ssq_hip.h"
+#include "cwt_kernels.h"
+#include "host_math.h"
+
+using namespace ssq;
+
+struct ssq_cwt_plan {
+  int dtype = SSQ_F32;
+  long long N = 0, P = 0, n1 = 0;
+  int logP = 0, log_p1 = 0, log_p2 = 0;
+  bool two_step = false, naive = false;
+  int wavelet = 0, padtype = 0, na = 0;
+  double dt = 1.0;
+  std::vector<double> scales;
+  void* d_psih = nullptr;      // [na][P/2+1] T
+  void* d_tw1 = nullptr;       // W_{P1}^i
+  void* d_tw2 = nullptr;       // W_{P2}^i
+  void* d_twhi = nullptr;      // W_P^(i<<12)
+  void* d_twlo = nullptr;      // W_P^i, i < 4096
+  void* d_scale_l1 = nullptr;  // [na] 1/P
+  void* d_scale_l2 = nullptr;  // [na] sqrt(a)/P
+  double* d_scales = nullptr;
+  int chunk = 1;               // scales per inverse-FFT chunk
+};
+
+namespace {
+
+const long double kPI = 3.14159265358979323846264338327950288L;
+
+template <typename T>
+int upload_tw(void** dst, long long n, long long P_total, long long stride) {
+  // dst[i] = exp(-2*pi*i * (i*stride) / P_total), i in [0, n)
+  std::vector<cpx<T>> h((size_t)(n > 0 ? n : 1));
+  for (long long i = 0; i < n; ++i) {
+    const long double ang = 2.0L * kPI * (long double)(i * stride) / (long double)P_total;
+    h[i] = {(T)cosl(ang), (T)(-sinl(ang))};
+  }
+  SSQ_HIP(hipMalloc(dst, sizeof(cpx<T>) * h.size()));
+  SSQ_HIP(hipMemcpy(*dst, h.data(), sizeof(cpx<T>) * h.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <typename T>
+int build_tables(ssq_cwt_plan* pl) {
+  const long long P1 = 1LL << pl->log_p1, P2 = 1LL << pl->log_p2;
+  if (int rc = upload_tw<T>(&pl->d_tw1, P1, P1, 1)) return rc;
+  if (int rc = upload_tw<T>(&pl->d_tw2, P2, P2, 1)) return rc;
+  const long long nlo = pl->P < 4096 ? pl->P : 4096;
+  const long long nhi = pl->P < 4096 ? 1 : pl->P / 4096;
+  if (int rc = upload_tw<T>(&pl->d_twlo, nlo, pl->P, 1)) return rc;
+  if (int rc = upload_tw<T>(&pl->d_twhi, nhi, pl->P, 4096)) return rc;
+  std::vector<T> s1((size_t)pl->na), s2((size_t)pl->na);
+  const double norm = 1.0 / (double)pl->P;                              // cwt.rs:251
+  for (int i = 0; i < pl->na; ++i) {
+    s1[i] = (T)norm;
+    s2[i] = (T)(norm * std::sqrt(pl->scales[i]));                       // cwt.rs:253
+  }
+  SSQ_HIP(hipMalloc(&pl->d_scale_l1, sizeof(T) * (pl->na > 0 ? pl->na : 1)));
+  SSQ_HIP(hipMalloc(&pl->d_scale_l2, sizeof(T) * (pl->na > 0 ? pl->na : 1)));
+  SSQ_HIP(hipMalloc((void**)&pl->d_scales, sizeof(double) * (pl->na > 0 ? pl->na : 1)));
+  if (pl->na > 0) {
+    SSQ_HIP(hipMemcpy(pl->d_scale_l1, s1.data(), sizeof(T) * pl->na, hipMemcpyHostToDevice));
+    SSQ_HIP(hipMemcpy(pl->d_scale_l2, s2.data(), sizeof(T) * pl->na, hipMemcpyHostToDevice));
+    SSQ_HIP(hipMemcpy(pl->d_scales, pl->scales.data(), sizeof(double) * pl->na, hipMemcpyHostToDevice));
+  }
+  const long long half = pl->P / 2;
+  SSQ_HIP(hipMalloc(&pl->d_psih, sizeof(T) * (size_t)((half + 1) * (pl->na > 0 ? pl->na : 1))));
+  if (pl->na > 0) {
+    SSQ_HIP(launch_wavelet_table<T>((T*)pl->d_psih, pl->d_scales, pl->na, pl->P, pl->wavelet, nullptr));
+    SSQ_HIP(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+struct WsLayout {
+  long long xh = 0, ybuf = 0, w = 0, dw = 0, total = 0;
+};
+WsLayout ws_layout(const ssq_cwt_plan* pl) {
+  const long long csz = pl->dtype == SSQ_F32 ? 8 : 16;
+  auto align = [](long long v) { return (v + 255) / 256 * 256; };
+  WsLayout L;
+  long long off = 0;
+  L.xh = off;
+  off += align(pl->P * csz);
+  L.ybuf = off;
+  off += align(pl->two_step ? (long long)pl->chunk * 2 * pl->P * csz : 0);
+  L.w = off;
+  off += align((long long)pl->na * pl->N * csz);
+  L.dw = off;
+  off += align((long long)pl->na * pl->N * csz);
+  L.total = off;
+  return L;
+}
+
+template <typename T>
+CwtDev<T> base_dev(const ssq_cwt_plan* pl, char* ws) {
+  const WsLayout L = ws_layout(pl);
+  CwtDev<T> p;
+  std::memset(&p, 0, sizeof(p));
+  p.xh = (cpx<T>*)(ws + L.xh);
+  p.ybuf = (cpx<T>*)(ws + L.ybuf);
+  p.psih = (const T*)pl->d_psih;
+  p.tw_hi = (const cpx<T>*)pl->d_twhi;
+  p.tw_lo = (const cpx<T>*)pl->d_twlo;
+  p.n_signal = pl->N;
+  p.P = pl->P;
+  p.n1 = pl->n1;
+  p.cols = pl->N;
+  p.log_p1 = pl->log_p1;
+  p.log_p2 = pl->log_p2;
+  p.padtype = pl->padtype;
+  p.n_kinds = 1;
+  p.n_transforms = 1;
+  // xi_k / dt = k * ((2*pi/P) / dt): base.rs:20-24 with cwt.rs:207
+  p.xi_step = (T)((1.0 * (2.0 * M_PI) / (double)pl->P) / pl->dt);
+  return p;
+}
+
+// forward FFT of the padded signal  (cwt.rs:87-95)
+template <typename T>
+int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t st) {
+  p.x = d_x;
+  p.n_transforms = 1;
+  if (pl->naive) {
+    SSQ_HIP(launch_cwt_naive_fwd<T>(p, st));
+  } else if (pl->two_step) {
+    p.tw_m = (const cpx<T>*)pl->d_tw1;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_A, p, st));
+    p.tw_m = (const cpx<T>*)pl->d_tw2;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_B, p, st));
+  } else {
+    p.tw_m = (const cpx<T>*)pl->d_tw1;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_S, p, st));
+  }
+  return 0;
+}
+
+// per-scale wavelet multiply + inverse FFT + normalise + unpad  (cwt.rs:228-310, :108-129)
+template <typename T>
+int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bool l1_norm, bool rpadded,
+                hipStream_t st) {
+  p.Wx = Wx;
+  p.dWx = dWx;
+  p.n_kinds = dWx ? 2 : 1;
+  p.rpadded = rpadded ? 1 : 0;
+  p.cols = rpadded ? pl->P : pl->N;
+  p.out_scale = (const T*)(l1_norm ? pl->d_scale_l1 : pl->d_scale_l2);
+  if (pl->naive) {
+    p.scale0 = 0;
+    p.n_transforms = pl->na * p.n_kinds;
+    SSQ_HIP(launch_cwt_naive_inv<T>(p, p.n_transforms, st));
+    return 0;
+  }
+  if (!pl->two_step) {
+    p.scale0 = 0;
+    p.n_transforms = pl->na * p.n_kinds;
+    p.tw_m = (const cpx<T>*)pl->d_tw1;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_INV_S, p, st));
+    return 0;
+  }
+  for (int s0 = 0; s0 < pl->na; s0 += pl->chunk) {
+    const int ns = (pl->na - s0 < pl->chunk) ? pl->na - s0 : pl->chunk;
+    p.scale0 = s0;
+    p.n_transforms = ns * p.n_kinds;
+    p.tw_m = (const cpx<T>*)pl->d_tw1;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
+    p.tw_m = (const cpx<T>*)pl->d_tw2;
+    SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+  }
+  return 0;
+}
+
+template <typename T>
+int exec_cwt_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, bool l1, bool rpadded, void* d_Wx,
+                   void* d_dWx, char* ws, hipStream_t st) {
+  const long long cols = rpadded ? pl->P : pl->N;
+  for (long long b = 0; b < batch; ++b) {
+    CwtDev<T> p = base_dev<T>(pl, ws);
+    if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
+    cpx<T>* W = (cpx<T>*)d_Wx + b * pl->na * cols;
+    cpx<T>* dW = d_dWx ? (cpx<T>*)d_dWx + b * pl->na * cols : nullptr;
+    if (int rc = run_inverse<T>(pl, p, W, dW, l1, rpadded, st)) return rc;
+  }
+  return 0;
+}
+
+template <typename T>
+int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_dist, int maprange,
+                   int squeezing, int flipud, double gamma, void* d_Tx, void* d_dbg_Wx, void* d_dbg_dWx,
+                   void* d_dbg_wk, char* ws, hipStream_t st) {
+  const WsLayout L = ws_layout(pl);
+  std::vector<double> f((size_t)pl->na);
+  if (int rc = ssq_cwt_ssq_freqs(pl->scales.data(), pl->na, pl->N, pl->dt, maprange, freq_dist, f.data()))
+    return rc;
+  const int n = pl->na;
+  CwtSsqDev<T> q;
+  std::memset(&q, 0, sizeof(q));
+  q.N = pl->N;
+  q.na = n;
+  q.is_log = (n > 1 && (f[1] / f[0] > 1.1)) ? 1 : 0;                      // ssq_cwt.rs:135-139
+  if (q.is_log) {                                                         // :142-149
+    const double lmin = std::log2(f[0]);
+    const double lstep = n > 1 ? (std::log2(f[n - 1]) - lmin) / (double)(n - 1) : 1.0;
+    q.bin_min = (T)lmin;
+    q.bin_step = (T)lstep;
+  } else {                                                                // :150-157
+    const double lin_min = f[0];
+    const double lstep = n > 1 ? (f[n - 1] - lin_min) / (double)(n - 1) : 1.0;
+    q.bin_min = (T)lin_min;
+    q.bin_step = (T)lstep;
+  }
+  q.squeezing = squeezing;
+  q.flipud = flipud;
+  q.gamma = (T)(gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma);       // ssq_cwt.rs:438-441
+  q.leb_val = (T)(1.0 / (double)n);
+  const long long plane = (long long)n * pl->N;
+  for (long long b = 0; b < batch; ++b) {
+    CwtDev<T> p = base_dev<T>(pl, ws);
+    if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
+    cpx<T>* W = (cpx<T>*)(ws + L.w);
+    cpx<T>* dW = (cpx<T>*)(ws + L.dw);
+    if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st)) return rc;   // ssq_cwt is always L1 (:405)
+    q.Wx = W;
+    q.dWx = dW;
+    q.Tx = (cpx<T>*)d_Tx + b * plane;
+    q.wk = d_dbg_wk ? (cpx<T>*)d_dbg_wk + b * plane : nullptr;
+    SSQ_HIP(hipMemsetAsync(q.Tx, 0, (size_t)plane * sizeof(cpx<T>), st));
+    SSQ_HIP(launch_cwt_reassign<T>(q, st));
+    if (d_dbg_Wx)
+      SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
+                             hipMemcpyDeviceToDevice, st));
+    if (d_dbg_dWx)
+      SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_dWx + b * plane, dW, (size_t)plane * sizeof(cpx<T>),
+                             hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet, const double* scales,
+                        int64_t na, double dt, int padtype) {
+  if (!plan) SSQ_FAIL("plan is NULL");
+  *plan = nullptr;
+  if (dtype != SSQ_F32 && dtype != SSQ_F64) SSQ_FAIL("dtype must be SSQ_F32 or SSQ_F64");
+  if (n_signal <= 0) SSQ_FAIL("empty input signal");
+  if (na < 0 || (na > 0 && !scales)) SSQ_FAIL("bad scales");
+  if (na > 32767) SSQ_FAIL("too many scales (max 32767)");
+  ssq_cwt_plan* pl = new ssq_cwt_plan();
+  pl->dtype = dtype;
+  pl->N = n_signal;
+  pl->P = host::next_power_of_2(n_signal + n_signal / 2);        // cwt.rs:87
+  pl->n1 = (pl->P - pl->N) / 2;                                  // cwt.rs:98
+  pl->wavelet = wavelet;
+  pl->padtype = padtype;
+  pl->na = (int)na;
+  pl->dt = dt;
+  pl->scales.assign(scales, scales + na);
+  int lp = 0;
+  while ((1LL << lp) < pl->P) ++lp;
+  pl->logP = lp;
+  if (lp > 24) {
+    delete pl;
+    SSQ_FAIL("signal too long: padded length above 2^24 is not supported yet");
+  }
+  if (lp < 4) {
+    pl->naive = true;
+    pl->log_p1 = lp;
+    pl->log_p2 = 0;
+  } else if (lp <= 12) {
+    pl->log_p1 = lp;
+    pl->log_p2 = 0;
+  } else {
+    pl->two_step = true;
+    pl->log_p2 = lp / 2;
+    pl->log_p1 = lp - pl->log_p2;
+  }
+  const long long csz = dtype == SSQ_F32 ? 8 : 16;
+  long long ch = (128LL << 20) / (2 * pl->P * csz);
+  if (ch < 1) ch = 1;
+  if (ch > (na > 0 ? na : 1)) ch = (na > 0 ? na : 1);
+  pl->chunk = (int)ch;
+  int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
+  if (rc) {
+    ssq_cwt_plan_destroy(pl);
+    return rc;
+  }
+  *plan = pl;
+  return 0;
+}
+
+int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
+  if (!pl) return 0;
+  hipFree(pl->d_psih);
+  hipFree(pl->d_tw1);
+  hipFree(pl->d_tw2);
+  hipFree(pl->d_twhi);
+  hipFree(pl->d_twlo);
+  hipFree(pl->d_scale_l1);
+  hipFree(pl->d_scale_l2);
+  hipFree(pl->d_scales);
+  delete pl;
+  return 0;
+}
+
+int64_t ssq_cwt_plan_workspace_bytes(const ssq_cwt_plan* pl, int64_t batch) {
+  (void)batch;   // signals of a batch are processed back to back through one workspace
+  if (!pl) return 0;
+  return ws_layout(pl).total;
+}
+
+int ssq_cwt_plan_exec_cwt(ssq_cwt_plan* pl, const void* d_x, int64_t batch, int l1_norm, int rpadded,
+                          void* d_Wx, void* d_dWx, void* d_workspace, int64_t workspace_bytes, void* stream) {
+  if (!pl) SSQ_FAIL("plan is NULL");
+  if (batch <= 0 || pl->na == 0) return 0;
+  if (!d_x || !d_Wx) SSQ_FAIL("device pointer is NULL");
+  if (!d_workspace || workspace_bytes < ws_layout(pl).total) SSQ_FAIL("workspace too small");
+  if (pl->dtype == SSQ_F32)
+    return exec_cwt_typed<float>(pl, d_x, batch, l1_norm != 0, rpadded != 0, d_Wx, d_dWx, (char*)d_workspace,
+                                 (hipStream_t)stream);
+  return exec_cwt_typed<double>(pl, d_x, batch, l1_norm != 0, rpadded != 0, d_Wx, d_dWx, (char*)d_workspace,
+                                (hipStream_t)stream);
+}
+
+int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* pl, const void* d_x, int64_t batch, int freq_dist, int maprange,
+                          int squeezing, int flipud, double gamma, void* d_Tx, void* d_dbg_Wx, void* d_dbg_dWx,
+                          void* d_dbg_wk, void* d_workspace, int64_t workspace_bytes, void* stream) {
+  if (!pl) SSQ_FAIL("plan is NULL");
+  if (pl->na == 0) SSQ_FAIL("index out of bounds: scales is empty (ssq_cwt.rs:459)");
+  if (batch <= 0) return 0;
+  if (!d_x || !d_Tx) SSQ_FAIL("device pointer is NULL");
+  if (!d_workspace || workspace_bytes < ws_layout(pl).total) SSQ_FAIL("workspace too small");
+  if (pl->dtype == SSQ_F32)
+    return exec_ssq_typed<float>(pl, d_x, batch, freq_dist, maprange, squeezing, flipud, gamma, d_Tx, d_dbg_Wx,
+                                 d_dbg_dWx, d_dbg_wk, (char*)d_workspace, (hipStream_t)stream);
+  return exec_ssq_typed<double>(pl, d_x, batch, freq_dist, maprange, squeezing, flipud, gamma, d_Tx, d_dbg_Wx,
+                                d_dbg_dWx, d_dbg_wk, (char*)d_workspace, (hipStream_t)stream);
+}
+
+// ---- host-pointer entry points -------------------------------------------------
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { hipFree(p); }
+  int alloc(long long bytes) {
+    if (bytes <= 0) bytes = 16;
+    SSQ_HIP(hipMalloc(&p, (size_t)bytes));
+    return 0;
+  }
+};
+struct PlanGuard {
+  ssq_cwt_plan* pl = nullptr;
+  ~PlanGuard() { ssq_cwt_plan_destroy(pl); }
+};
+}  // namespace
+
+int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, const double* scales,
+                 int64_t na, double dt, int l1_norm, int padtype, int rpadded, void* Wx, void* dWx) {
+  if (!x || !Wx) SSQ_FAIL("x or Wx is NULL");
+  if (batch <= 0) SSQ_FAIL("batch must be positive");
+  if (na == 0) return 0;
+  PlanGuard g;
+  if (int rc = ssq_cwt_plan_create(&g.pl, dtype, n_signal, wavelet, scales, na, dt, padtype)) return rc;
+  const long long esz = dtype == SSQ_F32 ? 4 : 8;
+  const long long cols = rpadded ? g.pl->P : n_signal;
+  const long long out_bytes = batch * na * cols * 2 * esz;
+  DevBuf dx, dW, ddW, ws;
+  if (int rc = dx.alloc(batch * n_signal * esz)) return rc;
+  if (int rc = dW.alloc(out_bytes)) return rc;
+  if (dWx)
+    if (int rc = ddW.alloc(out_bytes)) return rc;
+  const long long wsb = ssq_cwt_plan_workspace_bytes(g.pl, batch);
+  if (int rc = ws.alloc(wsb)) return rc;
+  SSQ_HIP(hipMemcpy(dx.p, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
+  if (int rc = ssq_cwt_plan_exec_cwt(g.pl, dx.p, batch, l1_norm, rpadded, dW.p, dWx ? ddW.p : nullptr, ws.p, wsb,
+                                     nullptr))
+    return rc;
+  SSQ_HIP(hipDeviceSynchronize());
+  SSQ_HIP(hipMemcpy(Wx, dW.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  if (dWx) SSQ_HIP(hipMemcpy(dWx, ddW.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet,
+                     const double* scales, int64_t na, double dt, int freq_dist, int maprange, int padtype,
+                     int squeezing, int flipud, double gamma, void* Tx, double* ssq_freqs, void* dbg_Wx,
+                     void* dbg_dWx, void* dbg_wk) {
+  if (!x || !Tx) SSQ_FAIL("x or Tx is NULL");
+  if (batch <= 0) SSQ_FAIL("batch must be positive");
+  if (na <= 0) SSQ_FAIL("index out of bounds: scales is empty (ssq_cwt.rs:459)");
+  PlanGuard g;
+  if (int rc = ssq_cwt_plan_create(&g.pl, dtype, n_signal, wavelet, scales, na, dt, padtype)) return rc;
+  const long long esz = dtype == SSQ_F32 ? 4 : 8;
+  const long long out_bytes = batch * na * n_signal * 2 * esz;
+  DevBuf dx, dT, d1, d2, d3, ws;
+  if (int rc = dx.alloc(batch * n_signal * esz)) return rc;
+  if (int rc = dT.alloc(out_bytes)) return rc;
+  if (dbg_Wx)
+    if (int rc = d1.alloc(out_bytes)) return rc;
+  if (dbg_dWx)
+    if (int rc = d2.alloc(out_bytes)) return rc;
+  if (dbg_wk)
+    if (int rc = d3.alloc(out_bytes)) return rc;
+  const long long wsb = ssq_cwt_plan_workspace_bytes(g.pl, batch);
+  if (int rc = ws.alloc(wsb)) return rc;
+  SSQ_HIP(hipMemcpy(dx.p, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
+  if (int rc = ssq_cwt_plan_exec_ssq(g.pl, dx.p, batch, freq_dist, maprange, squeezing, flipud, gamma, dT.p,
+                                     dbg_Wx ? d1.p : nullptr, dbg_dWx ? d2.p : nullptr,
+                                     dbg_wk ? d3.p : nullptr, ws.p, wsb, nullptr))
+    return rc;
+  SSQ_HIP(hipDeviceSynchronize());
+  SSQ_HIP(hipMemcpy(Tx, dT.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  if (dbg_Wx) SSQ_HIP(hipMemcpy(dbg_Wx, d1.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  if (dbg_dWx) SSQ_HIP(hipMemcpy(dbg_dWx, d2.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  if (dbg_wk) SSQ_HIP(hipMemcpy(dbg_wk, d3.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  if (ssq_freqs)
+    if (int rc = ssq_cwt_ssq_freqs(scales, na, n_signal, dt, maprange, freq_dist, ssq_freqs)) return rc;
+  return 0;
+}
+
+}  // extern "C"

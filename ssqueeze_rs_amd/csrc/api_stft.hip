@@ -1,0 +1,296 @@
+// api_stft.hip -- STFT-family plans and host entry points of the C-ABI (include/ssq_hip.h).
+// Replaces the PyO3 functions `stft` (rust/src/spectral/stft.rs:12-95) and `ssq_stft`
+// (rust/src/spectral/ssq_stft.rs:72-313).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ssq_hip.h"
+#include "host_math.h"
+#include "stft_kernels.h"
+
+using namespace ssq;
+
+struct ssq_stft_plan {
+  int dtype = SSQ_F32;
+  long long n_signal = 0;
+  int n_fft = 0, hop = 0, n_freqs = 0, n_frames = 0, pad_left = 0;
+  int padtype = 0, squeezing = 0;
+  double fs = 1.0, gamma = 0.0;
+  bool fused = false;
+  int tile_frames = 0;
+  int cu_count = 256;
+  // host-side fp64 quantities (reference expressions)
+  std::vector<double> ssq_freqs;   // ssq_stft.rs:42-54
+  double sfs_step = 0, dw = 0;
+  // device tables (typed by dtype)
+  void* d_tw = nullptr;
+  void* d_win2 = nullptr;
+  void* d_ssq_freqs = nullptr;
+  // generic-path tables (double)
+  double *d_g = nullptr, *d_gd = nullptr, *d_twre = nullptr, *d_twim = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::vector<double>& gdfs) {
+  const int n = pl->n_fft;
+  const long double PI = 3.14159265358979323846264338327950288L;
+  std::vector<cpx<T>> tw((size_t)n), win2((size_t)n);
+  std::vector<double> twre((size_t)n), twim((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const long double ang = 2.0L * PI * (long double)i / (long double)n;
+    twre[i] = (double)cosl(ang);
+    twim[i] = (double)(-sinl(ang));
+    tw[i] = {(T)twre[i], (T)twim[i]};
+    win2[i] = {(T)g[i], (T)gdfs[i]};
+  }
+  std::vector<T> fr((size_t)pl->n_freqs);
+  for (int i = 0; i < pl->n_freqs; ++i) fr[i] = (T)pl->ssq_freqs[i];
+  SSQ_HIP(hipMalloc(&pl->d_tw, sizeof(cpx<T>) * n));
+  SSQ_HIP(hipMalloc(&pl->d_win2, sizeof(cpx<T>) * n));
+  SSQ_HIP(hipMalloc(&pl->d_ssq_freqs, sizeof(T) * pl->n_freqs));
+  SSQ_HIP(hipMemcpy(pl->d_tw, tw.data(), sizeof(cpx<T>) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_win2, win2.data(), sizeof(cpx<T>) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_ssq_freqs, fr.data(), sizeof(T) * pl->n_freqs, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMalloc((void**)&pl->d_g, sizeof(double) * n));
+  SSQ_HIP(hipMalloc((void**)&pl->d_gd, sizeof(double) * n));
+  SSQ_HIP(hipMalloc((void**)&pl->d_twre, sizeof(double) * n));
+  SSQ_HIP(hipMalloc((void**)&pl->d_twim, sizeof(double) * n));
+  SSQ_HIP(hipMemcpy(pl->d_g, g.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_gd, gdfs.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_twre, twre.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_twim, twim.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <typename T>
+StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void* d_out, long long batch) {
+  StftDev<T> p;
+  p.x = (const T*)d_x;
+  p.out = (cpx<T>*)d_out;
+  p.tw = (const cpx<T>*)pl->d_tw;
+  p.win2 = (const cpx<T>*)pl->d_win2;
+  p.ssq_freqs = (const T*)pl->d_ssq_freqs;
+  p.n_signal = pl->n_signal;
+  p.n_frames = pl->n_frames;
+  p.n_freqs = pl->n_freqs;
+  p.hop = pl->hop;
+  p.pad_left = pl->pad_left;
+  p.padtype = pl->padtype;
+  const int F = pl->tile_frames > 0 ? pl->tile_frames : 1;
+  p.tiles_per_signal = (pl->n_frames + F - 1) / F;
+  p.total_tiles = (long long)p.tiles_per_signal * batch;
+  p.out_kind = out_kind;
+  p.squeezing = pl->squeezing;
+  p.sfs_step = (T)pl->sfs_step;
+  p.dw = (T)pl->dw;
+  p.inv_dw = (T)(1.0 / pl->dw);
+  p.gamma2 = (T)(pl->gamma * pl->gamma);
+  p.leb_val = (T)((1.0 / (double)pl->n_freqs) * pl->dw);
+  p.f_last = (T)pl->ssq_freqs[pl->n_freqs - 1];
+  return p;
+}
+
+template <typename T>
+int exec_typed(ssq_stft_plan* pl, int out_kind, const void* d_x, long long batch, void* d_out,
+               void* d_ws, long long ws_bytes, hipStream_t stream) {
+  StftDev<T> p = make_dev<T>(pl, out_kind, d_x, d_out, batch);
+  if (pl->fused) {
+    SSQ_HIP(launch_stft_fused<T>(p, pl->n_fft, pl->cu_count, stream));
+    return 0;
+  }
+  const long long bins = batch * (long long)pl->n_freqs * pl->n_frames;
+  const long long need = ssq_stft_plan_workspace_bytes(pl, batch, out_kind);
+  if (need > 0 && (!d_ws || ws_bytes < need)) SSQ_FAIL("workspace too small for the generic STFT path");
+  GenericTabs tabs{pl->d_g, pl->d_gd, pl->d_twre, pl->d_twim};
+  cpx<T>* ws = (cpx<T>*)d_ws;
+  if (out_kind == SSQ_OUT_SX) {
+    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
+                                 pl->padtype, pl->n_frames, tabs, (cpx<T>*)d_out, nullptr, stream));
+  } else if (out_kind == SSQ_OUT_DSX) {
+    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
+                                 pl->padtype, pl->n_frames, tabs, ws, (cpx<T>*)d_out, stream));
+  } else {
+    cpx<T>* Sx = ws;
+    cpx<T>* dSx = ws + bins;
+    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
+                                 pl->padtype, pl->n_frames, tabs, Sx, dSx, stream));
+    SSQ_HIP(hipMemsetAsync(d_out, 0, (size_t)bins * sizeof(cpx<T>), stream));
+    SSQ_HIP(launch_reassign_cols<T>(p, Sx, dSx, batch, stream));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, const double* window,
+                         int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing,
+                         double gamma, int force_generic) {
+  if (!plan) SSQ_FAIL("plan is NULL");
+  *plan = nullptr;
+  if (dtype != SSQ_F32 && dtype != SSQ_F64) SSQ_FAIL("dtype must be SSQ_F32 or SSQ_F64");
+  if (!window) SSQ_FAIL("window is NULL");
+  if (n_fft > (1 << 24)) SSQ_FAIL("n_fft too large");
+  int64_t nf = 0, nfr = 0;
+  if (int rc = ssq_stft_shape(n_signal, n_fft, hop, &nf, &nfr)) return rc;
+  if (nfr > 0x7fffffff) SSQ_FAIL("too many frames");
+  ssq_stft_plan* pl = new ssq_stft_plan();
+  pl->dtype = dtype;
+  pl->n_signal = n_signal;
+  pl->n_fft = (int)n_fft;
+  pl->hop = (int)hop;
+  pl->n_freqs = (int)nf;
+  pl->n_frames = (int)nfr;
+  pl->pad_left = (int)((n_fft - 1) / 2);                     // stft_utils.rs:21-22
+  pl->padtype = padtype;
+  pl->squeezing = squeezing;
+  pl->fs = fs;
+  pl->gamma = gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma;   // ssq_stft.rs:258-261
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    pl->cu_count = prop.multiProcessorCount;
+  // reference expressions, fp64
+  pl->ssq_freqs.resize((size_t)nf);
+  for (int64_t i = 0; i < nf; ++i)
+    pl->ssq_freqs[i] = ((double)i * 0.5 * fs) / ((double)nf - 1.0);          // ssq_stft.rs:50
+  pl->dw = nf > 1 ? pl->ssq_freqs[1] - pl->ssq_freqs[0] : 0.0;               // ssq_stft.rs:273
+  pl->sfs_step = nf > 1 ? (0.5 * fs - 0.0) / (double)(nf - 1) : 0.0;         // ssq_stft.rs:255 (linspace)
+  std::vector<double> g(window, window + n_fft);
+  std::vector<double> gd = host::diff_window(g.data(), n_fft);               // ssq_stft.rs:131-179
+  for (auto& v : gd) v *= fs;                                                // ssq_stft.rs:208
+  const bool f32 = dtype == SSQ_F32;
+  pl->fused = !force_generic && (f32 ? fused_supported<float>((int)n_fft) : fused_supported<double>((int)n_fft));
+  pl->tile_frames = pl->fused ? (f32 ? fused_tile_frames<float>((int)n_fft) : fused_tile_frames<double>((int)n_fft)) : 1;
+  int rc = f32 ? upload_tables<float>(pl, g, gd) : upload_tables<double>(pl, g, gd);
+  if (rc) {
+    ssq_stft_plan_destroy(pl);
+    return rc;
+  }
+  *plan = pl;
+  return 0;
+}
+
+int ssq_stft_plan_destroy(ssq_stft_plan* pl) {
+  if (!pl) return 0;
+  hipFree(pl->d_tw);
+  hipFree(pl->d_win2);
+  hipFree(pl->d_ssq_freqs);
+  hipFree(pl->d_g);
+  hipFree(pl->d_gd);
+  hipFree(pl->d_twre);
+  hipFree(pl->d_twim);
+  delete pl;
+  return 0;
+}
+
+int ssq_stft_plan_is_fused(const ssq_stft_plan* pl) { return pl && pl->fused ? 1 : 0; }
+
+int64_t ssq_stft_plan_workspace_bytes(const ssq_stft_plan* pl, int64_t batch, int out_kind) {
+  if (!pl || pl->fused) return 0;
+  const int64_t elem = (pl->dtype == SSQ_F32 ? 8 : 16);
+  const int64_t bins = batch * (int64_t)pl->n_freqs * pl->n_frames;
+  if (out_kind == SSQ_OUT_SX) return 0;
+  if (out_kind == SSQ_OUT_DSX) return bins * elem;
+  return 2 * bins * elem;
+}
+
+int ssq_stft_plan_exec(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t batch, void* d_out,
+                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+  if (!pl) SSQ_FAIL("plan is NULL");
+  if (batch <= 0) return 0;
+  if (!d_x || !d_out) SSQ_FAIL("device pointer is NULL");
+  if (out_kind < SSQ_OUT_TX || out_kind > SSQ_OUT_WK) SSQ_FAIL("bad out_kind");
+  if ((out_kind == SSQ_OUT_TX || out_kind == SSQ_OUT_WK) && pl->n_freqs < 2)
+    SSQ_FAIL("index out of bounds: ssq_freqs[1] with fewer than 2 bins (ssq_stft.rs:273)");
+  if (pl->dtype == SSQ_F32)
+    return exec_typed<float>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+  return exec_typed<double>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Shared body of the two host entry points: upload x, run the requested outputs, download.
+static int run_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
+                    int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing, double gamma,
+                    int n_out, const int* kinds, void* const* outs) {
+  if (!x) SSQ_FAIL("x is NULL");
+  if (batch <= 0) SSQ_FAIL("batch must be positive");
+  ssq_stft_plan* pl = nullptr;
+  if (int rc = ssq_stft_plan_create(&pl, dtype, n_signal, window, n_fft, hop, fs, padtype, squeezing, gamma, 0))
+    return rc;
+  const int64_t esz = dtype == SSQ_F32 ? 4 : 8;
+  const int64_t bins = batch * (int64_t)pl->n_freqs * pl->n_frames;
+  void *d_x = nullptr, *d_out = nullptr, *d_ws = nullptr;
+  int rc = 0;
+  int64_t ws = 0;
+  for (int i = 0; i < n_out; ++i) {
+    const int64_t w = ssq_stft_plan_workspace_bytes(pl, batch, kinds[i]);
+    if (outs[i] && w > ws) ws = w;
+  }
+  auto cleanup = [&]() {
+    hipFree(d_x);
+    hipFree(d_out);
+    hipFree(d_ws);
+    ssq_stft_plan_destroy(pl);
+  };
+#define SSQ_TRY(call)                                                        \
+  do {                                                                       \
+    hipError_t e__ = (call);                                                 \
+    if (e__ != hipSuccess) {                                                 \
+      ssq::set_error(std::string(#call) + ": " + hipGetErrorString(e__));    \
+      cleanup();                                                             \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+  SSQ_TRY(hipMalloc(&d_x, (size_t)(batch * n_signal * esz)));
+  SSQ_TRY(hipMalloc(&d_out, (size_t)(bins * 2 * esz)));
+  if (ws > 0) SSQ_TRY(hipMalloc(&d_ws, (size_t)ws));
+  SSQ_TRY(hipMemcpy(d_x, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
+  for (int i = 0; i < n_out && rc == 0; ++i) {
+    if (!outs[i]) continue;
+    rc = ssq_stft_plan_exec(pl, kinds[i], d_x, batch, d_out, d_ws, ws, nullptr);
+    if (rc) break;
+    SSQ_TRY(hipDeviceSynchronize());
+    SSQ_TRY(hipMemcpy(outs[i], d_out, (size_t)(bins * 2 * esz), hipMemcpyDeviceToHost));
+  }
+#undef SSQ_TRY
+  cleanup();
+  return rc;
+}
+
+int ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
+                  int64_t n_fft, int64_t hop, int padtype, void* Sx, double* freqs) {
+  if (!Sx) SSQ_FAIL("Sx is NULL");
+  const int kinds[1] = {SSQ_OUT_SX};
+  void* outs[1] = {Sx};
+  if (int rc = run_host(dtype, x, batch, n_signal, window, n_fft, hop, 1.0, padtype, 0, -1.0, 1, kinds, outs))
+    return rc;
+  if (freqs) {                                               // stft.rs:40 linspace(0, 0.5, n_freqs)
+    const int64_t nf = n_fft / 2 + 1;
+    const double step = nf > 1 ? 0.5 / (double)(nf - 1) : 0.0;
+    for (int64_t i = 0; i < nf; ++i) freqs[i] = 0.0 + step * (double)i;
+  }
+  return 0;
+}
+
+int ssq_ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
+                      int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing, double gamma,
+                      void* Tx, double* ssq_freqs, void* dbg_Sx, void* dbg_dSx, void* dbg_wk) {
+  if (!Tx) SSQ_FAIL("Tx is NULL");
+  if (n_fft / 2 + 1 < 2) SSQ_FAIL("index out of bounds: ssq_freqs[1] with fewer than 2 bins (ssq_stft.rs:273)");
+  const int kinds[4] = {SSQ_OUT_TX, SSQ_OUT_SX, SSQ_OUT_DSX, SSQ_OUT_WK};
+  void* outs[4] = {Tx, dbg_Sx, dbg_dSx, dbg_wk};
+  if (int rc = run_host(dtype, x, batch, n_signal, window, n_fft, hop, fs, padtype, squeezing, gamma, 4, kinds, outs))
+    return rc;
+  if (ssq_freqs) {
+    const int64_t nf = n_fft / 2 + 1;
+    for (int64_t i = 0; i < nf; ++i) ssq_freqs[i] = ((double)i * 0.5 * fs) / ((double)nf - 1.0);
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// cwt_kernels.h -- device parameter blocks + launch entry points of the CWT family.
+#pragma once
+#include "ssq_common.h"
+
+namespace ssq {
+
+// What a tile-FFT launch loads and stores (see cwt_kernels.hip).
+enum CwtMode {
+  CWT_FWD_A = 0,   // padded real signal -> column FFTs (+ W_P twiddle) -> ybuf
+  CWT_FWD_B = 1,   // ybuf rows -> row FFTs -> xh (natural order)
+  CWT_FWD_S = 2,   // P <= 4096: padded real signal -> xh in one step
+  CWT_INV_A = 3,   // xh * psih (* i*xi/dt) -> column iFFTs (+ conj twiddle) -> ybuf
+  CWT_INV_B = 4,   // ybuf rows -> row iFFTs -> Wx / dWx (scaled, unpadded)
+  CWT_INV_S = 5    // P <= 4096: xh * psih -> Wx / dWx in one step
+};
+
+template <typename T>
+struct CwtDev {
+  const T* x;            // [n_signal] one real signal
+  cpx<T>* xh;            // [P] FFT of the padded signal             (cwt.rs:147-162)
+  cpx<T>* ybuf;          // [transforms in chunk][P] step-A output
+  const T* psih;         // [na][P/2+1] wavelet table                 (cwt.rs:492-547)
+  const cpx<T>* tw_m;    // W_M^i for the transform length of this launch
+  const cpx<T>* tw_hi;   // W_P^(i << 12)
+  const cpx<T>* tw_lo;   // W_P^i, i < 4096
+  const T* out_scale;    // [na] 1/P (* sqrt(a) if !l1_norm)          (cwt.rs:251-262)
+  cpx<T>* Wx;            // [na][cols]
+  cpx<T>* dWx;           // [na][cols] or NULL
+  long long n_signal;
+  long long P;           // padded length (power of two)
+  long long n1;          // (P - N)/2                                 (cwt.rs:98)
+  long long cols;        // N, or P when rpadded
+  int log_p1, log_p2;    // P = P1 * P2 (two-step) ; single step: log_p1 = log P, log_p2 = 0
+  int padtype;
+  int rpadded;
+  int scale0;            // first scale of this chunk
+  int n_kinds;           // 1 (Wx) or 2 (Wx and dWx)
+  int n_transforms;      // transforms in this launch (chunk scales * kinds; 1 for forward)
+  T xi_step;             // (2*pi/P)/dt : xi_k/dt = k * xi_step      (wavelets/base.rs:18-33, cwt.rs:207)
+};
+
+template <typename T>
+hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream);
+
+// wavelet table psih[s][k] = psi_hat(scale_s * 2*pi*k/P), k in [0, P/2]   (cwt.rs:492-547)
+template <typename T>
+hipError_t launch_wavelet_table(T* psih, const double* d_scales, int na, long long P, int wavelet,
+                                hipStream_t stream);
+
+// any-P fallback for tiny signals (P < 64): direct sums
+template <typename T>
+hipError_t launch_cwt_naive_fwd(const CwtDev<T>& p, hipStream_t stream);
+template <typename T>
+hipError_t launch_cwt_naive_inv(const CwtDev<T>& p, int na, hipStream_t stream);
+
+template <typename T>
+struct CwtSsqDev {
+  const cpx<T>* Wx;      // [na][N]
+  const cpx<T>* dWx;     // [na][N]
+  cpx<T>* Tx;            // [na][N]
+  cpx<T>* wk;            // [na][N] (w, k or -1) or NULL
+  long long N;
+  int na;
+  int is_log;            // ssq_cwt.rs:135-139
+  int squeezing;
+  int flipud;
+  T bin_min;             // log2(f0) or f0                           (ssq_cwt.rs:142-158)
+  T bin_step;
+  T gamma;
+  T leb_val;             // 1/na                                      (ssq_cwt.rs:201-204)
+};
+template <typename T>
+hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream);
+
+}  // namespace ssq

@@ -1,0 +1,75 @@
+// fft_core.h -- the per-lane FFT core shared by the STFT and CWT kernels (gfx950).
+//
+// A length-N = 2^LOGN transform is held by L = N/16 lanes, 16 complex values per lane
+// (lane t owns elements t + L*q).  Stockham autosort: every pass does in-register radix-16
+// (last pass: the remainder radix) butterflies, then one exchange through an LDS row of
+// N + N/16 elements.  After the last pass lane t holds X[t + L*q] in natural order.
+// For L <= 64 a transform lives inside one wavefront and the exchange needs no block barrier.
+#pragma once
+#include <utility>
+#include "ssq_common.h"
+
+namespace ssq {
+
+__device__ __forceinline__ int exch_phys(int idx) { return idx + (idx >> 4); }
+
+template <bool MULTIWAVE>
+__device__ __forceinline__ void frame_sync() {
+  if (MULTIWAVE) {
+    __syncthreads();
+  } else {
+    // a frame lives in one wavefront: the LDS unit executes a wave's DS ops in order, so a
+    // compiler-level ordering point is all that is needed between the writes and the reads
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool INV, int R, int NB, typename T, int... Bs>
+__device__ __forceinline__ void butterflies(cpx<T> (&v)[16], std::integer_sequence<int, Bs...>) {
+  (dft_strided<INV, R, Bs, NB>(v), ...);
+}
+
+// One Stockham pass P of the 16-elements-per-lane FFT (see ssq_common.h pass tables).
+template <typename T, int LOGN, int P, bool INV, bool TW_REGS, bool MULTIWAVE>
+__device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cpx<T> (&twr)[3][16],
+                                         const cpx<T>* __restrict__ tw_tab, int t) {
+  constexpr int N = 1 << LOGN, L = N / 16;
+  constexpr int NP = num_passes(LOGN);
+  constexpr int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
+  if constexpr (P > 0) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int m = 1; m < R; ++m) {
+        cpx<T> w;
+        if constexpr (TW_REGS) {
+          w = twr[P - 1][b + m * NB];
+        } else {
+          const int k = (t + L * b) & (NS - 1);
+          w = tw_tab[k * m * (N / (NS * R))];
+        }
+        if (INV) w.y = -w.y;
+        v[b + m * NB] = cmul(v[b + m * NB], w);
+      }
+    }
+  }
+  butterflies<INV, R, NB>(v, std::make_integer_sequence<int, NB>{});
+  if constexpr (P < NP - 1) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int j = t + L * b;
+      const int k = j & (NS - 1);
+      const int base = (j - k) * R + k;
+#pragma unroll
+      for (int u = 0; u < R; ++u) exch[exch_phys(base + u * NS)] = v[b + u * NB];
+    }
+    frame_sync<MULTIWAVE>();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = exch[exch_phys(t + L * q)];
+    frame_sync<MULTIWAVE>();
+    fft_pass<T, LOGN, P + 1, INV, TW_REGS, MULTIWAVE>(v, exch, twr, tw_tab, t);
+  }
+}
+
+}  // namespace ssq

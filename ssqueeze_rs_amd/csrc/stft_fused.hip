@@ -1,0 +1,271 @@
+// stft_fused.hip -- fused STFT / synchrosqueezed-STFT kernel for gfx950 (MI355X).
+//
+// One launch does, per tile of F consecutive frames of one signal:
+//   reflect/zero padding by index mirroring   (stft_utils.rs:19-65)
+//   window and diff-window multiply, packed as z = x*g + i*x*g'*fs
+//                                              (stft_utils.rs:7-16, ssq_stft.rs:202-211)
+//   ONE complex n_fft-point FFT per frame (the reference does two, ssq_stft.rs:226-227),
+//   unpacked as Sx = (Z[k]+conj Z[N-k])/2, dSx = (Z[k]-conj Z[N-k])/(2i)
+//   phase transform + nearest-bin index        (ssq_stft.rs:11-39, :280-289)
+//   scatter-accumulate Tx[k, frame] += Sx*dw   (ssq_stft.rs:292-298) into an LDS tile
+//   coalesced row-segment stores of the tile   (replaces the strided gather at :247-252)
+// so HBM traffic is the algorithmic minimum: x once in, Tx (or Sx) once out.
+//
+// Work decomposition (CDNA4): a frame's N = 2^LOGN points are held by L = N/16 lanes,
+// 16 complex values per lane (lane t owns elements t + L*q).  The FFT is a Stockham
+// autosort with in-register radix-16 butterflies and one LDS exchange between passes;
+// for N <= 1024 a frame lives inside one wavefront, so the exchanges need no block
+// barrier.  The N-k partner for the real-pair unpack comes by ds_bpermute, not LDS.
+// The Tx tile is two fp planes [n_freqs][F+1] (odd pitch => the per-frame scatter's
+// ds_add_f32 spread over all 32 banks).
+#include "fft_core.h"
+#include "stft_kernels.h"
+
+namespace ssq {
+
+template <typename T, int LOGN>
+struct FusedCfg {
+  static constexpr int N = 1 << LOGN;
+  static constexpr int L = N / 16;                         // lanes per frame
+  static constexpr int W = (sizeof(T) == 4) ? 8 : 4;       // waves per block
+  static constexpr int FPW = (L >= 64) ? 1 : 64 / L;       // frames per wave
+  static constexpr int WPF = (L <= 64) ? 1 : L / 64;       // waves per frame
+  static constexpr int FIF = W * FPW / WPF;                // frames in flight per block
+  static constexpr int NF = N / 2 + 1;
+  static constexpr int EXCH_ELEMS = N + N / 16;            // +1 element per 16: bank spread
+  static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)sizeof(cpx<T>);
+  static constexpr int LDS_MAX = 160 * 1024;
+  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES) / (2 * NF * (int)sizeof(T)) - 1;
+  static constexpr int FT = (sizeof(T) == 4) ? 16 : 8;     // target: >=128-B row segments
+  static constexpr int FCAP = (FT < FMAX) ? FT : FMAX;
+  static constexpr int F = (FIF >= FT) ? FIF : (FCAP / FIF) * FIF;
+  static constexpr int PITCH = F + 1;
+  static constexpr int PLANE = NF * PITCH;                 // elements per plane
+  static constexpr int TILE_BYTES = ((2 * PLANE * (int)sizeof(T) + 15) / 16) * 16;
+  static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES;
+  static constexpr int NP = num_passes(LOGN);
+  static constexpr bool TW_REGS = (sizeof(T) == 4);
+  static constexpr bool WIN_REGS = (sizeof(T) == 4) && (N <= 1024);
+  static_assert(F >= FIF && F % FIF == 0, "tile must hold whole in-flight groups");
+  static_assert(LDS_BYTES <= LDS_MAX, "LDS budget");
+};
+
+template <typename T, int LOGN>
+__global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
+  using C = FusedCfg<T, LOGN>;
+  constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
+  constexpr bool MULTIWAVE = (C::WPF > 1);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
+  T* tile_re = reinterpret_cast<T*>(smem);
+  T* tile_im = tile_re + C::PLANE;
+  cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int slot, t;
+  if constexpr (L <= 64) {
+    slot = wave * C::FPW + lane / L;
+    t = lane % L;
+  } else {
+    slot = wave / C::WPF;
+    t = (wave % C::WPF) * 64 + lane;
+  }
+  cpx<T>* exch = exch_all + slot * C::EXCH_ELEMS;
+
+  // ---- per-lane constants, live across all tiles this block processes ----
+  cpx<T> twr[3][16];
+  if constexpr (C::TW_REGS) {
+#pragma unroll
+    for (int P = 1; P < C::NP; ++P) {
+      const int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+#pragma unroll
+        for (int m = 1; m < 16; ++m) {
+          if (b < NB && m < R) {
+            const int k = (t + L * b) & (NS - 1);
+            twr[P - 1][b + m * NB] = p.tw[k * m * (N / (NS * R))];
+          }
+        }
+      }
+    }
+  }
+  cpx<T> winr[16];
+  if constexpr (C::WIN_REGS) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) winr[q] = p.win2[t + L * q];
+  }
+
+  // zero the tile once; afterwards the read-out pass re-zeroes what it reads
+  for (int i = tid; i < 2 * C::PLANE; i += C::W * 64) tile_re[i] = (T)0;
+  __syncthreads();
+
+  const T half = (T)0.5;
+  for (long long tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const long long sig = tile / p.tiles_per_signal;
+    const int frame0 = (int)(tile % p.tiles_per_signal) * F;
+    const T* __restrict__ xs = p.x + sig * p.n_signal;
+    const long long first = (long long)frame0 * p.hop - p.pad_left;
+    const bool interior = (first >= 0) && (first + (long long)(F - 1) * p.hop + N <= p.n_signal) &&
+                          (frame0 + F <= p.n_frames);
+
+#pragma unroll 1
+    for (int it = 0; it < F / C::FIF; ++it) {
+      const int fl = it * C::FIF + slot;          // frame index inside the tile
+      const int frame = frame0 + fl;
+      const bool valid = frame < p.n_frames;
+      const long long pos0 = (long long)frame * p.hop - p.pad_left + t;
+
+      cpx<T> v[16];
+      if (interior) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const T xv = xs[pos0 + L * q];
+          const cpx<T> wq = C::WIN_REGS ? winr[q] : p.win2[t + L * q];
+          v[q] = {xv * wq.x, xv * wq.y};
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const T xv = valid ? load_padded(xs, pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+          const cpx<T> wq = C::WIN_REGS ? winr[q] : p.win2[t + L * q];
+          v[q] = {xv * wq.x, xv * wq.y};
+        }
+      }
+
+      fft_pass<T, LOGN, 0, false, C::TW_REGS, MULTIWAVE>(v, exch, twr, p.tw, t);
+      // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
+
+      // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
+      cpx<T> zp[9];
+      if constexpr (!MULTIWAVE) {
+        const int src = (lane - t) + ((L - t) & (L - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          cpx<T> r;
+          r.x = __shfl(v[15 - q].x, src);
+          r.y = __shfl(v[15 - q].y, src);
+          if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
+          zp[q] = r;
+        }
+        zp[8] = v[8];                              // k = N/2 pairs with itself (t == 0 only)
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = t + L * q;
+          zp[q] = exch[exch_phys((N - k) & (N - 1))];
+        }
+        zp[8] = v[8];
+        __syncthreads();
+      }
+
+      // ---- unpack, phase transform, reassignment ----
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (q == 8 && t != 0) break;
+        const int k = t + L * q;
+        const cpx<T> zk = v[q], zn = zp[q];
+        const cpx<T> S = {half * (zk.x + zn.x), half * (zk.y - zn.y)};
+        const cpx<T> dS = {half * (zk.y + zn.y), half * (zn.x - zk.x)};
+        if (!valid) continue;
+        const int o = k * PITCH + fl;
+        if (p.out_kind == 1) {                     // SSQ_OUT_SX
+          tile_re[o] = S.x;
+          tile_im[o] = S.y;
+        } else if (p.out_kind == 2) {              // SSQ_OUT_DSX
+          tile_re[o] = dS.x;
+          tile_im[o] = dS.y;
+        } else {
+          T w;
+          int kk;
+          const bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+          if (p.out_kind == 3) {                   // SSQ_OUT_WK
+            tile_re[o] = w;
+            tile_im[o] = keep ? (T)kk : (T)-1;
+          } else if (keep) {                       // SSQ_OUT_TX
+            const int d = kk * PITCH + fl;
+            if (p.squeezing == 1) {
+              atomicAdd(&tile_re[d], p.leb_val);
+            } else {
+              atomicAdd(&tile_re[d], S.x * p.dw);
+              atomicAdd(&tile_im[d], S.y * p.dw);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
+    cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0;
+    for (int i = tid; i < NF * F; i += C::W * 64) {
+      const int k = i / F, f = i % F;
+      const int o = k * PITCH + f;
+      const cpx<T> val = {tile_re[o], tile_im[o]};
+      tile_re[o] = (T)0;
+      tile_im[o] = (T)0;
+      if (frame0 + f < p.n_frames) og[(long long)k * p.n_frames + f] = val;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ launch ----
+template <typename T>
+bool fused_supported(int n_fft) {
+  return n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0;
+}
+
+template <typename T, int LOGN>
+static hipError_t launch_one(const StftDev<T>& p, int cu_count, hipStream_t stream) {
+  using C = FusedCfg<T, LOGN>;
+  int per_cu = C::LDS_MAX / C::LDS_BYTES;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu * C::W > 32) per_cu = 32 / C::W;
+  long long blocks = (long long)cu_count * per_cu;
+  if (blocks > p.total_tiles) blocks = p.total_tiles;
+  if (blocks < 1) return hipSuccess;
+  hipLaunchKernelGGL((stft_fused_kernel<T, LOGN>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
+  return hipGetLastError();
+}
+
+template <typename T>
+int fused_tile_frames(int n_fft) {
+  switch (n_fft) {
+    case 64: return FusedCfg<T, 6>::F;
+    case 128: return FusedCfg<T, 7>::F;
+    case 256: return FusedCfg<T, 8>::F;
+    case 512: return FusedCfg<T, 9>::F;
+    case 1024: return FusedCfg<T, 10>::F;
+    case 2048: return FusedCfg<T, 11>::F;
+    case 4096: return FusedCfg<T, 12>::F;
+  }
+  return 0;
+}
+
+template <typename T>
+hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, hipStream_t stream) {
+  switch (n_fft) {
+    case 64: return launch_one<T, 6>(p, cu_count, stream);
+    case 128: return launch_one<T, 7>(p, cu_count, stream);
+    case 256: return launch_one<T, 8>(p, cu_count, stream);
+    case 512: return launch_one<T, 9>(p, cu_count, stream);
+    case 1024: return launch_one<T, 10>(p, cu_count, stream);
+    case 2048: return launch_one<T, 11>(p, cu_count, stream);
+    case 4096: return launch_one<T, 12>(p, cu_count, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+template bool fused_supported<float>(int);
+template bool fused_supported<double>(int);
+template int fused_tile_frames<float>(int);
+template int fused_tile_frames<double>(int);
+template hipError_t launch_stft_fused<float>(const StftDev<float>&, int, int, hipStream_t);
+template hipError_t launch_stft_fused<double>(const StftDev<double>&, int, int, hipStream_t);
+
+}  // namespace ssq

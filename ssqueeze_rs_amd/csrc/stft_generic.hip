@@ -1,0 +1,105 @@
+// stft_generic.hip -- unfused STFT-family kernels for ANY n_fft (the reference takes any
+// length rustfft can plan, i.e. any n: stft.rs:43-44, ssq_stft.rs:198-199).  Used when the
+// fused LDS-tile kernel does not apply (n_fft not a power of two, < 64 or > 4096) and as an
+// independent second GPU implementation in the parity tests.
+//
+//   dft_frames_kernel    : Sx/dSx[k, frame] by direct O(n_fft) sums per output bin with an
+//                          exact-index twiddle table (double accumulation for both dtypes)
+//                          (stft.rs:47-85, ssq_stft.rs:191-252)
+//   reassign_cols_kernel : one thread per time column, rows ascending -- the reference's own
+//                          accumulation order, no atomics (ssq_stft.rs:276-301)
+#include "stft_kernels.h"
+
+namespace ssq {
+
+template <typename T>
+__global__ void dft_frames_kernel(const T* __restrict__ x, long long n_signal, int n_fft, int hop,
+                                  int pad_left, int padtype, int n_frames, int n_freqs,
+                                  GenericTabs tabs, cpx<T>* __restrict__ Sx, cpx<T>* __restrict__ dSx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;   // frame
+  const int k = blockIdx.y * blockDim.y + threadIdx.y;   // bin
+  const long long b = blockIdx.z;
+  if (j >= n_frames || k >= n_freqs) return;
+  const T* xs = x + b * n_signal;
+  const long long pos0 = (long long)j * hop - pad_left;
+  double sr = 0, si = 0, dr = 0, di = 0;
+  int idx = 0;                                            // (n*k) mod n_fft
+  for (int n = 0; n < n_fft; ++n) {
+    const double xv = (double)load_padded(xs, pos0 + n, n_signal, padtype);
+    const double c = tabs.tw_re[idx], s = tabs.tw_im[idx];
+    const double u = xv * tabs.g[n];
+    sr += u * c;
+    si += u * s;
+    if (dSx) {
+      const double v = xv * tabs.gd[n];
+      dr += v * c;
+      di += v * s;
+    }
+    idx += k;
+    if (idx >= n_fft) idx -= n_fft;
+  }
+  const long long o = (b * n_freqs + k) * (long long)n_frames + j;
+  Sx[o] = {(T)sr, (T)si};
+  if (dSx) dSx[o] = {(T)dr, (T)di};
+}
+
+template <typename T>
+__global__ void reassign_cols_kernel(StftDev<T> p, const cpx<T>* __restrict__ Sx,
+                                     const cpx<T>* __restrict__ dSx) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long b = blockIdx.y;
+  if (j >= p.n_frames) return;
+  const long long base = b * (long long)p.n_freqs * p.n_frames + j;
+  for (int i = 0; i < p.n_freqs; ++i) {
+    const long long o = base + (long long)i * p.n_frames;
+    const cpx<T> S = Sx[o], dS = dSx[o];
+    T w;
+    int kk;
+    const bool keep = phase_bin<T>(p, i, S, dS, w, kk);
+    if (p.out_kind == 3) {
+      p.out[o] = {w, keep ? (T)kk : (T)-1};
+    } else if (keep) {
+      const long long d = base + (long long)kk * p.n_frames;
+      cpx<T> acc = p.out[d];
+      if (p.squeezing == 1) {
+        acc.x += p.leb_val;
+      } else {
+        acc.x += S.x * p.dw;
+        acc.y += S.y * p.dw;
+      }
+      p.out[d] = acc;
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_dft_frames(const T* x, long long batch, long long n_signal, int n_fft, int hop,
+                             int pad_left, int padtype, int n_frames, const GenericTabs& tabs,
+                             cpx<T>* Sx, cpx<T>* dSx, hipStream_t stream) {
+  const int n_freqs = n_fft / 2 + 1;
+  dim3 block(64, 4, 1);
+  dim3 grid((n_frames + 63) / 64, (n_freqs + 3) / 4, (unsigned)batch);
+  hipLaunchKernelGGL(dft_frames_kernel<T>, grid, block, 0, stream, x, n_signal, n_fft, hop, pad_left,
+                     padtype, n_frames, n_freqs, tabs, Sx, dSx);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx<T>* dSx,
+                                long long batch, hipStream_t stream) {
+  dim3 block(64, 1, 1);
+  dim3 grid((p.n_frames + 63) / 64, (unsigned)batch, 1);
+  hipLaunchKernelGGL(reassign_cols_kernel<T>, grid, block, 0, stream, p, Sx, dSx);
+  return hipGetLastError();
+}
+
+template hipError_t launch_dft_frames<float>(const float*, long long, long long, int, int, int, int, int,
+                                             const GenericTabs&, cpx<float>*, cpx<float>*, hipStream_t);
+template hipError_t launch_dft_frames<double>(const double*, long long, long long, int, int, int, int, int,
+                                              const GenericTabs&, cpx<double>*, cpx<double>*, hipStream_t);
+template hipError_t launch_reassign_cols<float>(const StftDev<float>&, const cpx<float>*, const cpx<float>*,
+                                                long long, hipStream_t);
+template hipError_t launch_reassign_cols<double>(const StftDev<double>&, const cpx<double>*,
+                                                 const cpx<double>*, long long, hipStream_t);
+
+}  // namespace ssq

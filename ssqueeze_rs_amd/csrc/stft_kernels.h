@@ -1,0 +1,136 @@
+// stft_kernels.h -- device parameter block + launch entry points of the STFT family.
+#pragma once
+#include "ssq_common.h"
+
+namespace ssq {
+
+// Device-side parameters of one STFT-family launch (passed by value).
+template <typename T>
+struct StftDev {
+  const T* x;              // [batch][n_signal]
+  cpx<T>* out;             // [batch][n_freqs][n_frames]
+  const cpx<T>* tw;        // W_N^i = exp(-2*pi*i*i/N), i in [0, N)
+  const cpx<T>* win2;      // (g[n], g'[n]*fs)
+  const T* ssq_freqs;      // [n_freqs] reference expression (ssq_stft.rs:50), exact fix-up table
+  long long n_signal;
+  long long total_tiles;
+  int n_frames;
+  int n_freqs;
+  int hop;
+  int pad_left;            // (n_fft-1)/2   stft_utils.rs:22
+  int padtype;
+  int tiles_per_signal;
+  int out_kind;            // SSQ_OUT_*
+  int squeezing;
+  T sfs_step;              // Sfs[i] = i*sfs_step          (ssq_stft.rs:255)
+  T dw;                    // ssq_freqs[1]-ssq_freqs[0]    (ssq_stft.rs:273)
+  T inv_dw;
+  T gamma2;                // gamma^2 (|Sx| < gamma  <=>  |Sx|^2 < gamma^2)
+  T leb_val;               // (1/n_freqs)*dw               (ssq_stft.rs:294,298)
+  T f_last;                // ssq_freqs[n_freqs-1]
+};
+
+// fused LDS-tile kernel (stft_fused.hip): 64 <= n_fft <= 4096, power of two
+template <typename T>
+bool fused_supported(int n_fft);
+template <typename T>
+int fused_tile_frames(int n_fft);          // frames per output tile (F)
+template <typename T>
+hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, hipStream_t stream);
+
+// generic any-n_fft kernels (stft_generic.hip); tables are always double
+struct GenericTabs {
+  const double* g;       // [n_fft]
+  const double* gd;      // [n_fft]  g' * fs
+  const double* tw_re;   // [n_fft]  cos(2*pi*i/n)
+  const double* tw_im;   // [n_fft] -sin(2*pi*i/n)
+};
+template <typename T>
+hipError_t launch_dft_frames(const T* x, long long batch, long long n_signal, int n_fft, int hop,
+                             int pad_left, int padtype, int n_frames, const GenericTabs& tabs,
+                             cpx<T>* Sx, cpx<T>* dSx /*nullable*/, hipStream_t stream);
+// Sx,dSx -> out (Tx or WK), thread per time column, rows ascending (reference order, no atomics)
+template <typename T>
+hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx<T>* dSx,
+                                long long batch, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// Phase transform + bin index shared by the fused and the generic kernels.
+//   w  = |Sfs[i] - Im(dSx/Sx)/(2*pi)|           ssq_stft.rs:23-33
+//   kk = first argmin_idx |w - ssq_freqs[idx]|   ssq_stft.rs:280-289
+// Returns false when the bin is skipped (|Sx| < gamma or w infinite, :23,:278).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
+  const T den = S.x * S.x + S.y * S.y;
+  const T num = dS.y * S.x - dS.x * S.y;
+  const T two_pi = (T)6.283185307179586;
+  T pd;
+  if constexpr (sizeof(T) == 4) {
+    pd = num * __builtin_amdgcn_rcpf(den * two_pi);
+  } else {
+    pd = num / (den * two_pi);
+  }
+  const T sfs = (T)i * p.sfs_step;
+  T w = fabs(sfs - pd);
+  const bool skip = (den < p.gamma2) || isinf(w);
+  if (den < p.gamma2) w = (T)INFINITY;
+  w_out = w;
+  const int last = p.n_freqs - 1;
+  int kk;
+  if constexpr (sizeof(T) == 4) {
+    // fp32 mode semantics (documented in DESIGN.md): u = fma(w, 1/dw, -0.5), kk = ceil(u)
+    // clamped to [0, n_freqs-1]; exact half-bin ties go to the lower bin like the scan's strict `<`.
+    const T u = __builtin_fmaf(w, p.inv_dw, (T)-0.5);
+    kk = (u >= (T)last) ? last : (int)__builtin_ceilf(u);
+    if (w != w) kk = 0;          // NaN never wins the scan: k stays 0
+  } else {
+    const T tq = w / p.dw;
+    const T u = tq - (T)0.5;
+    kk = (u >= (T)last) ? last : (int)ceil(u);
+    if (w != w) {
+      kk = 0;
+    } else if (!skip) {
+      const T fr = fabs(tq - floor(tq) - (T)0.5);
+      if (w > p.f_last) {
+        // fl(w - f_k) may tie for several k: the scan keeps the FIRST minimum.
+        const T target = fabs(w - p.ssq_freqs[last]);
+        int lo = 0, hi = last;            // smallest k with |w - f_k| == target (dist non-increasing in k)
+        if (last > 0 && fabs(w - p.ssq_freqs[last - 1]) != target) {
+          lo = last;
+        } else {
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (fabs(w - p.ssq_freqs[mid]) == target) hi = mid; else lo = mid + 1;
+          }
+        }
+        kk = lo;
+      } else if (fr < (T)1e-7) {
+        // near a half-bin tie: decide with the reference's own distance expression
+        int k0 = kk - 2 < 0 ? 0 : kk - 2;
+        int k1 = kk + 2 > last ? last : kk + 2;
+        T best = (T)INFINITY;
+        int bk = 0;
+        for (int c = k0; c <= k1; ++c) {
+          const T d = fabs(w - p.ssq_freqs[c]);
+          if (d < best) { best = d; bk = c; }
+        }
+        kk = bk;
+      }
+    }
+  }
+  kk_out = kk;
+  return !skip;
+}
+
+// padded sample fetch: stft_utils.rs:19-65 by index mirroring (no padded copy)
+template <typename T>
+__device__ __forceinline__ T load_padded(const T* __restrict__ xs, long long m, long long n, int padtype) {
+  if (m >= 0 && m < n) return xs[m];
+  if (padtype != 0) return (T)0;
+  long long mm = (m < 0) ? -m : (2 * n - 2 - m);
+  if (mm >= 0 && mm < n) return xs[mm];
+  return (T)0;
+}
+
+}  // namespace ssq

@@ -1,0 +1,180 @@
+"""GPU parity tests of the CWT family (cwt / cwt_simd / ssq_cwt) against the NumPy oracle.
+
+Tolerances: fp64 |dWx|/max|Wx| <= 1e-11; fp32 <= 1e-5 (length-P FFTs up to 2^15 here and an
+un-normalised GMW).  Reassignment bins: exact given the kernel's own w except
+within 1e-6 (fp64) of a rounding boundary; Tx is compared after re-accumulation with the
+kernel's own bins.
+"""
+import numpy as np
+import pytest
+
+from oracle import ssq_oracle as o
+from ssqueeze_rs_amd import _rs
+
+pytestmark = pytest.mark.gpu
+
+
+def _sig(N, seed=0, dtype=np.float64):
+    return o.synth_signal(N, seed, dtype)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_cwt_reference_smoke_shapes():
+    """tests/cwt_test.py:17-66: 1 kHz / 100 Hz sine, scales = logspace(1,5,32)/fs, GMW;
+    the one thing the reference states: Wx.shape == (len(scales), len(x))."""
+    fs = 1000
+    t = np.linspace(0, 1, fs, endpoint=False)
+    x = np.sin(2 * np.pi * 100 * t)
+    scales = np.logspace(1, 5, 32) / fs
+    Wx, sc, dWx = _rs.cwt(x, wavelet="gmw", scales=scales, fs=fs, nv=16, l1_norm=True, derivative=True)
+    assert Wx.shape == (32, 1000) and dWx.shape == (32, 1000) and np.array_equal(sc, scales)
+    Wx_o, _, dWx_o = o.cwt(x, "gmw", scales=scales, fs=fs, nv=16, derivative=True)
+    assert _rel(Wx, Wx_o) <= 1e-11 and _rel(dWx, dWx_o) <= 1e-11
+    out = _rs.cwt(x, wavelet="gmw", scales=scales, fs=fs)       # derivative=False: still a 3-tuple
+    assert len(out) == 3 and out[2] is None
+
+
+@pytest.mark.parametrize("N", [5, 11, 40, 300, 1000, 2730, 2731, 6000, 20000])
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+def test_cwt_f64_sizes(N, wavelet):
+    """N <= 10: P < 16 direct sums; N <= 2730: one-step LDS FFT; above: two-step FFT."""
+    x = _sig(N, 1)
+    Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, nv=4, derivative=True) if N >= 40 else \
+        _rs.cwt(x, wavelet=wavelet, scales=np.array([1.0, 2.0, 3.5]), derivative=True)
+    kw = dict(nv=4) if N >= 40 else dict(scales=np.array([1.0, 2.0, 3.5]))
+    Wx_o, sc_o, dWx_o = o.cwt(x, wavelet, derivative=True, **kw)
+    assert Wx.shape == Wx_o.shape
+    assert np.array_equal(sc, sc_o)
+    assert _rel(Wx, Wx_o) <= 1e-11, N
+    assert _rel(dWx, dWx_o) <= 1e-11, N
+
+
+def test_cwt_options_f64():
+    x = _sig(3000, 2)
+    sc = 2.0 ** np.linspace(1, 9, 24)
+    for kw in (dict(l1_norm=False), dict(rpadded=True), dict(padtype="zero"), dict(fs=250.0),
+               dict(t=np.arange(3000) * 0.004), dict(l1_norm=False, rpadded=True, derivative=True)):
+        a = _rs.cwt(x, wavelet="morlet", scales=sc, **kw)
+        b = o.cwt(x, "morlet", scales=sc, **kw)
+        assert a[0].shape == b[0].shape
+        assert _rel(a[0], b[0]) <= 1e-11, kw
+        if kw.get("derivative"):
+            assert _rel(a[2], b[2]) <= 1e-11
+    # cwt_simd: same numbers, scale generation via exp(p*ln2)
+    a = _rs.cwt_simd(x, wavelet="morlet", nv=8)
+    b = o.cwt_simd(x, "morlet", nv=8)
+    assert np.array_equal(a[1], b[1]) and _rel(a[0], b[0]) <= 1e-11
+    with pytest.raises(ValueError):
+        _rs.cwt(x, t=np.array([0.0]))
+
+
+@pytest.mark.parametrize("N", [1000, 20000])
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+def test_cwt_f32(N, wavelet):
+    x = _sig(N, 3, np.float32)
+    Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, nv=4, derivative=True)
+    assert Wx.dtype == np.complex64
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), wavelet, nv=4, derivative=True)
+    assert _rel(Wx, Wx_o) <= 1e-5
+    assert _rel(dWx, dWx_o) <= 1e-5
+
+
+def _check_ssq_cwt(x, tol_w, **kw):
+    Tx, f, dbg = _rs.ssq_cwt(x, _debug=True, **kw)
+    Tx_o, f_o, im = o.ssq_cwt(x.astype(np.float64), return_intermediates=True, **kw)
+    assert Tx.shape == Tx_o.shape == (im["scales"].shape[0], x.shape[0])
+    assert np.array_equal(f, f_o)
+    wmax = np.abs(im["Wx"]).max()
+    assert np.abs(dbg["Wx"] - im["Wx"]).max() <= tol_w * wmax
+    assert np.abs(dbg["dWx"] - im["dWx"]).max() <= tol_w * np.abs(im["dWx"]).max()
+    # bins from the kernel's own w through the oracle's binning (ssq_cwt.rs:135-196)
+    w_g = dbg["w"].astype(np.float64)
+    b, valid, is_log = o.cwt_bins(w_g, f_o)
+    flipud = kw.get("flipud", True)
+    na = Tx.shape[0]
+    k_model = np.where(valid, (na - 1 - b) if flipud else b, -1)
+    mism = k_model != dbg["k"]
+    if mism.any():
+        # only allowed at a rounding boundary of the bin formula (fp32 evaluates it in fp32)
+        with np.errstate(all="ignore"):
+            if is_log:
+                lmin = np.log2(f_o[0]); lstep = (np.log2(f_o[-1]) - lmin) / (na - 1)
+                v = (np.log2(w_g[mism]) - lmin) / lstep
+            else:
+                lstep = (f_o[-1] - f_o[0]) / (na - 1)
+                v = (w_g[mism] - f_o[0]) / lstep
+        tie_tol = 1e-6 if x.dtype == np.float64 else 2e-3
+        assert (np.abs(np.abs(v - np.trunc(v)) - 0.5) < tie_tol).all(), f"{mism.sum()} unexplained"
+        assert mism.mean() <= (1e-4 if x.dtype == np.float64 else 5e-3)
+    keep = dbg["k"] >= 0
+    # scatter: re-accumulate with the kernel's own bins (no dw factor in the CWT path)
+    Tx_re = np.zeros_like(Tx_o)
+    cols = np.arange(x.shape[0])
+    leb = kw.get("squeezing") == "lebesgue"
+    Wg = dbg["Wx"].astype(np.complex128)
+    for i in range(na):
+        m = keep[i]
+        if leb:
+            Tx_re[dbg["k"][i, m], cols[m]] += 1.0 / na
+        else:
+            Tx_re[dbg["k"][i, m], cols[m]] += Wg[i, m]
+    assert np.abs(Tx - Tx_re).max() <= (1e-10 if x.dtype == np.float64 else 2e-5) * max(np.abs(Tx_re).max(), 1e-300)
+    # end to end: column sums are invariant under bin flips (not under keep/drop flips)
+    same_keep = (keep == im["valid"]).all(axis=0)
+    if not leb:
+        d = np.abs(Tx.sum(0) - Tx_o.sum(0))[same_keep]
+        assert d.max(initial=0.0) <= (1e-9 if x.dtype == np.float64 else 1e-3) * wmax
+    assert same_keep.mean() >= 0.98
+    return dbg, im
+
+
+def test_ssq_cwt_reference_smoke():
+    """tests/ssq_cwt_test.py:17-63: Tx.shape == (len(scales), len(x)); is_log path (ratio 1.346)."""
+    fs = 1000
+    t = np.linspace(0, 1, fs, endpoint=False)
+    x = np.sin(2 * np.pi * 100 * t)
+    scales = np.logspace(1, 5, 32) / fs
+    dbg, im = _check_ssq_cwt(x, 1e-11, wavelet="gmw", scales=scales, fs=fs, nv=16, padtype="reflect",
+                             squeezing="sum", maprange="peak")
+    assert im["is_log"]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(wavelet="morlet", nv=8),                                   # 64+ log scales: is_log False quirk
+    dict(wavelet="morlet", nv=8, flipud=False),
+    dict(wavelet="morlet", nv=8, maprange="maximal"),
+    dict(wavelet="morlet", nv=8, ssq_freqs="linear"),
+    dict(wavelet="morlet", nv=8, squeezing="lebesgue"),
+    dict(wavelet="gmw", nv=2, fs=100.0),                            # few scales: is_log True
+    dict(wavelet="morlet", nv=8, padtype="zero", gamma=1e-2),
+])
+def test_ssq_cwt_f64_options(kw):
+    _check_ssq_cwt(_sig(4096, 4), 1e-11, **kw)
+
+
+def test_ssq_cwt_f64_two_step():
+    _check_ssq_cwt(_sig(12000, 5), 1e-11, wavelet="morlet", nv=4)
+
+
+@pytest.mark.parametrize("kw", [dict(wavelet="morlet", nv=8), dict(wavelet="gmw", nv=2, fs=100.0)])
+def test_ssq_cwt_f32(kw):
+    _check_ssq_cwt(_sig(4096, 6, np.float32), 1e-5, **kw)
+    _check_ssq_cwt(_sig(12000, 6, np.float32), 1e-5, **kw)
+
+
+def test_ssq_cwt_batch_and_errors():
+    xb = np.stack([_sig(2000, b) for b in range(3)])
+    Tb, f = _rs.ssq_cwt(xb, wavelet="morlet", nv=4)
+    for b in range(3):
+        T1, _ = _rs.ssq_cwt(xb[b], wavelet="morlet", nv=4)
+        assert np.array_equal(Tb[b], T1)
+    with pytest.raises(ValueError):
+        _rs.ssq_cwt(xb[0], t=np.array([1.0]))
+    with pytest.raises(TypeError):
+        _rs.ssq_cwt(xb[0], ssq_freqs=np.arange(4.0))     # a string in the reference (ssq_cwt.rs:268)
+    a, _ = _rs.ssq_cwt(xb[0], wavelet="nonsense", nv=4)  # unknown wavelet -> gmw (cwt.rs:522)
+    b, _ = _rs.ssq_cwt(xb[0], wavelet="gmw", nv=4)
+    assert np.array_equal(a, b)
