@@ -24,6 +24,7 @@ struct ssq_stft_plan {
   // host-side fp64 quantities (reference expressions)
   std::vector<double> ssq_freqs;   // ssq_stft.rs:42-54
   double sfs_step = 0, dw = 0;
+  double alpha = 1.0;              // power of two: scales the derivative channel of the packed FFT
   // device tables (typed by dtype)
   void* d_tw = nullptr;
   void* d_win2 = nullptr;
@@ -45,7 +46,7 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
     twre[i] = (double)cosl(ang);
     twim[i] = (double)(-sinl(ang));
     tw[i] = {(T)twre[i], (T)twim[i]};
-    win2[i] = {(T)g[i], (T)gdfs[i]};
+    win2[i] = {(T)g[i], (T)(gdfs[i] * pl->alpha)};
   }
   std::vector<T> fr((size_t)pl->n_freqs);
   for (int i = 0; i < pl->n_freqs; ++i) fr[i] = (T)pl->ssq_freqs[i];
@@ -91,6 +92,7 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.gamma2 = (T)(pl->gamma * pl->gamma);
   p.leb_val = (T)((1.0 / (double)pl->n_freqs) * pl->dw);
   p.f_last = (T)pl->ssq_freqs[pl->n_freqs - 1];
+  p.inv_alpha = (T)(1.0 / pl->alpha);
   return p;
 }
 
@@ -164,6 +166,21 @@ int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, cons
   std::vector<double> g(window, window + n_fft);
   std::vector<double> gd = host::diff_window(g.data(), n_fft);               // ssq_stft.rs:131-179
   for (auto& v : gd) v *= fs;                                                // ssq_stft.rs:208
+  {
+    // The fused kernel packs z = x*g + i*x*g'*fs*alpha into one complex FFT.  alpha (a power of
+    // two, so exact) makes the two channels the same magnitude: otherwise the small channel
+    // inherits the rounding error of the large one (fp32: |g'| ~ |g|*pi/n_fft, times fs).
+    double mg = 0, md = 0;
+    for (int64_t i = 0; i < n_fft; ++i) {
+      mg = std::fmax(mg, std::fabs(g[i]));
+      md = std::fmax(md, std::fabs(gd[i]));
+    }
+    if (mg > 0 && md > 0 && std::isfinite(mg / md)) {
+      int e = 0;
+      std::frexp(mg / md, &e);
+      pl->alpha = std::ldexp(1.0, e - 1);
+    }
+  }
   const bool f32 = dtype == SSQ_F32;
   pl->fused = !force_generic && (f32 ? fused_supported<float>((int)n_fft) : fused_supported<double>((int)n_fft));
   pl->tile_frames = pl->fused ? (f32 ? fused_tile_frames<float>((int)n_fft) : fused_tile_frames<double>((int)n_fft)) : 1;

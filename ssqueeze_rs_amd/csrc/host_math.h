@@ -14,6 +14,13 @@ using cd = std::complex<double>;
 
 inline bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// 2.0_f64.powf(p) (cwt.rs:485, ssq_cwt.rs:72): call libm pow through a volatile pointer so the
+// compiler cannot rewrite pow(2, p) as exp2(p) (the two differ in the last ulp)
+inline double pow2f(double p) {
+  static double (*volatile fn)(double, double) = static_cast<double (*)(double, double)>(std::pow);
+  return fn(2.0, p);
+}
+
 // in-place radix-2 FFT, n a power of two; sign = -1 forward, +1 inverse (unnormalised)
 inline void fft_pow2(std::vector<cd>& a, int sign) {
   const size_t n = a.size();
@@ -139,7 +146,7 @@ inline std::vector<double> log_scales(int64_t N, int64_t nv, bool simd_variant) 
   std::vector<double> s((size_t)num);
   for (int64_t i = 0; i < num; ++i) {
     const double p = log_min + (double)i * sf;
-    s[i] = (simd_variant && num >= 16) ? std::exp(p * M_LN2) : std::pow(2.0, p);
+    s[i] = (simd_variant && num >= 16) ? std::exp(p * M_LN2) : pow2f(p);
   }
   return s;
 }
@@ -153,7 +160,7 @@ inline std::vector<double> cwt_ssq_freqs(int64_t n, double fmin, double fmax, bo
   } else {
     const double lmin = std::log2(fmin), lmax = std::log2(fmax);
     const double sf = n > 1 ? (lmax - lmin) / (double)(n - 1) : 0.0;
-    for (int64_t i = 0; i < n; ++i) f[i] = std::pow(2.0, lmin + (double)i * sf);
+    for (int64_t i = 0; i < n; ++i) f[i] = pow2f(lmin + (double)i * sf);
   }
   return f;
 }

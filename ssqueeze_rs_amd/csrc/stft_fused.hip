@@ -102,6 +102,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   __syncthreads();
 
   const T half = (T)0.5;
+  const T dhalf = (T)0.5 * p.inv_alpha;
   for (long long tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
     const long long sig = tile / p.tiles_per_signal;
     const int frame0 = (int)(tile % p.tiles_per_signal) * F;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         const int k = t + L * q;
         const cpx<T> zk = v[q], zn = zp[q];
         const cpx<T> S = {half * (zk.x + zn.x), half * (zk.y - zn.y)};
-        const cpx<T> dS = {half * (zk.y + zn.y), half * (zn.x - zk.x)};
+        const cpx<T> dS = {dhalf * (zk.y + zn.y), dhalf * (zn.x - zk.x)};
         if (!valid) continue;
         const int o = k * PITCH + fl;
         if (p.out_kind == 1) {                     // SSQ_OUT_SX

@@ -123,11 +123,13 @@ def _check_ssq_cwt(x, tol_w, **kw):
             Tx_re[dbg["k"][i, m], cols[m]] += Wg[i, m]
     assert np.abs(Tx - Tx_re).max() <= (1e-10 if x.dtype == np.float64 else 2e-5) * max(np.abs(Tx_re).max(), 1e-300)
     # end to end: column sums are invariant under bin flips (not under keep/drop flips)
-    same_keep = (keep == im["valid"]).all(axis=0)
+    # keep/drop may only differ where Wx is rounding noise (the un-normalised GMW leaves ~1e17*eps there)
+    flips = keep != im["valid"]
+    noise = (1e-9 if x.dtype == np.float64 else 2e-4) * wmax
+    assert np.abs(im["Wx"][flips]).max(initial=0.0) <= noise
     if not leb:
-        d = np.abs(Tx.sum(0) - Tx_o.sum(0))[same_keep]
-        assert d.max(initial=0.0) <= (1e-9 if x.dtype == np.float64 else 1e-3) * wmax
-    assert same_keep.mean() >= 0.98
+        d = np.abs(Tx.sum(0) - Tx_o.sum(0))
+        assert d.max(initial=0.0) <= (1e-9 if x.dtype == np.float64 else 1e-3) * wmax + flips.sum(0).max() * noise
     return dbg, im
 
 

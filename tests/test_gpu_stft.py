@@ -150,7 +150,7 @@ def _check_ssq_f32(x32, win, n_fft, hop, fs, pad="reflect", squeezing="sum"):
     assert np.array_equal(f, f_o)
     smax = np.abs(im["Sx"]).max()
     assert np.abs(dbg["Sx"] - im["Sx"]).max() <= 4e-6 * smax
-    assert np.abs(dbg["dSx"] - im["dSx"]).max() <= 4e-6 * np.abs(im["dSx"]).max()
+    assert np.abs(dbg["dSx"] - im["dSx"]).max() <= 6e-6 * np.abs(im["dSx"]).max()
     keep_g = dbg["k"] >= 0
     # (a) w: the kernel's own Sx/dSx through the reference formula
     Sg, dSg = dbg["Sx"].astype(np.complex128), dbg["dSx"].astype(np.complex128)
