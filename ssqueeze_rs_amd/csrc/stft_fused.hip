@@ -16,8 +16,14 @@
 // autosort with in-register radix-16 butterflies and one LDS exchange between passes;
 // for N <= 1024 a frame lives inside one wavefront, so the exchanges need no block
 // barrier.  The N-k partner for the real-pair unpack comes by ds_bpermute, not LDS.
-// The Tx tile is two fp planes [n_freqs][F+1] (odd pitch => the per-frame scatter's
-// ds_add_f32 spread over all 32 banks).
+// The Tx tile is two planes [n_freqs][F+1] (odd pitch => the per-frame scatter spreads over all
+// 32 banks) that accumulate FIXED POINT: LDS float atomics cost ~3 cycles per LANE on gfx950
+// (187 cycles per wave instruction, measured: tools/ubench/lds_atomics.hip) while integer LDS
+// atomics run at ~4 cycles per wave instruction.  Each column (frame) gets its own power-of-two
+// scale 2^(FRAC-e) with 2^e > the column's L1 mass, so no partial sum can overflow, the
+// quantisation step (2^-30 resp. 2^-62 of the column's L1 mass) sits below the FFT's own
+// rounding error, and -- integer adds being associative -- the result is bitwise reproducible.
+#include <type_traits>
 #include "fft_core.h"
 #include "stft_kernels.h"
 
@@ -35,13 +41,17 @@ struct FusedCfg {
   static constexpr int EXCH_ELEMS = N + N / 16;            // +1 element per 16: bank spread
   static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)sizeof(cpx<T>);
   static constexpr int LDS_MAX = 160 * 1024;
-  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES) / (2 * NF * (int)sizeof(T)) - 1;
+  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
   static constexpr int FT = (sizeof(T) == 4) ? 16 : 8;     // target: >=128-B row segments
   static constexpr int FCAP = (FT < FMAX) ? FT : FMAX;
   static constexpr int F = (FIF >= FT) ? FIF : (FCAP / FIF) * FIF;
   static constexpr int PITCH = F + 1;
   static constexpr int PLANE = NF * PITCH;                 // elements per plane
-  static constexpr int TILE_BYTES = ((2 * PLANE * (int)sizeof(T) + 15) / 16) * 16;
+  static constexpr int TILE_BYTES = (((2 * PLANE + F) * (int)sizeof(T) + 15) / 16) * 16;   // + col_scale[F]
+  using IT = std::conditional_t<sizeof(T) == 4, int, long long>;
+  using UT = std::conditional_t<sizeof(T) == 4, unsigned int, unsigned long long>;
+  static constexpr int FRAC = (sizeof(T) == 4) ? 30 : 62;      // fixed-point fraction bits
+  static constexpr int EMIN = (sizeof(T) == 4) ? -90 : -960;   // keeps 2^(FRAC-e) finite
   static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES;
   static constexpr int NP = num_passes(LOGN);
   static constexpr bool TW_REGS = (sizeof(T) == 4);
@@ -50,14 +60,55 @@ struct FusedCfg {
   static_assert(LDS_BYTES <= LDS_MAX, "LDS budget");
 };
 
+
+// bit casts between T and its integer twin (debug outputs travel through the integer tile)
+template <typename T>
+__device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> as_int(T v) {
+  if constexpr (sizeof(T) == 4) return __float_as_int(v);
+  else return __double_as_longlong(v);
+}
+template <typename T>
+__device__ __forceinline__ T from_int(std::conditional_t<sizeof(T) == 4, int, long long> v) {
+  if constexpr (sizeof(T) == 4) return __int_as_float(v);
+  else return __longlong_as_double(v);
+}
+template <typename T>
+__device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> to_fixed(T v) {
+  if constexpr (sizeof(T) == 4) return __float2int_rn(v);
+  else return __double2ll_rn(v);
+}
+
+// sum of `v` over the L lanes that hold one frame (all of them get the total)
+template <typename T, int L, bool MULTIWAVE>
+__device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
+  constexpr int LW = (L < 64) ? L : 64;
+#pragma unroll
+  for (int m = LW / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  if constexpr (MULTIWAVE) {
+    // a frame spans L/64 waves: combine the wave totals through the frame's (idle) exchange row
+    __syncthreads();
+    if (lane == 0) scratch[t >> 6] = v;
+    __syncthreads();
+    T s = (T)0;
+#pragma unroll
+    for (int w = 0; w < L / 64; ++w) s += scratch[w];
+    __syncthreads();
+    v = s;
+  }
+  return v;
+}
+
 template <typename T, int LOGN>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
   constexpr bool MULTIWAVE = (C::WPF > 1);
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
-  T* tile_re = reinterpret_cast<T*>(smem);
-  T* tile_im = tile_re + C::PLANE;
+  using IT = typename C::IT;                     // integer twin of T: the tile accumulates fixed point
+  using UT = typename C::UT;
+  IT* tile_re = reinterpret_cast<IT*>(smem);
+  IT* tile_im = tile_re + C::PLANE;
+  T* col_scale = reinterpret_cast<T*>(tile_im + C::PLANE);     // [F] 2^(e-FRAC) per column
   cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES);
 
   const int tid = threadIdx.x;
@@ -98,7 +149,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   }
 
   // zero the tile once; afterwards the read-out pass re-zeroes what it reads
-  for (int i = tid; i < 2 * C::PLANE; i += C::W * 64) tile_re[i] = (T)0;
+  for (int i = tid; i < 2 * C::PLANE; i += C::W * 64) tile_re[i] = 0;
   __syncthreads();
 
   const T half = (T)0.5;
@@ -165,36 +216,63 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       }
 
       // ---- unpack, phase transform, reassignment ----
+      cpx<T> S[9];
+      int kk[9];
+      bool keep[9];
+      T l1 = (T)0;                                // this lane's share of the column's L1 mass (x dw)
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
+        keep[q] = false;
+        kk[q] = 0;
         if (q == 8 && t != 0) break;
         const int k = t + L * q;
         const cpx<T> zk = v[q], zn = zp[q];
-        const cpx<T> S = {half * (zk.x + zn.x), half * (zk.y - zn.y)};
+        S[q] = {half * (zk.x + zn.x), half * (zk.y - zn.y)};
         const cpx<T> dS = {dhalf * (zk.y + zn.y), dhalf * (zn.x - zk.x)};
         if (!valid) continue;
         const int o = k * PITCH + fl;
         if (p.out_kind == 1) {                     // SSQ_OUT_SX
-          tile_re[o] = S.x;
-          tile_im[o] = S.y;
+          tile_re[o] = as_int<T>(S[q].x);
+          tile_im[o] = as_int<T>(S[q].y);
         } else if (p.out_kind == 2) {              // SSQ_OUT_DSX
-          tile_re[o] = dS.x;
-          tile_im[o] = dS.y;
+          tile_re[o] = as_int<T>(dS.x);
+          tile_im[o] = as_int<T>(dS.y);
         } else {
           T w;
-          int kk;
-          const bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+          keep[q] = phase_bin<T>(p, k, S[q], dS, w, kk[q]);
           if (p.out_kind == 3) {                   // SSQ_OUT_WK
-            tile_re[o] = w;
-            tile_im[o] = keep ? (T)kk : (T)-1;
-          } else if (keep) {                       // SSQ_OUT_TX
-            const int d = kk * PITCH + fl;
+            tile_re[o] = as_int<T>(w);
+            tile_im[o] = as_int<T>(keep[q] ? (T)kk[q] : (T)-1);
+          } else if (keep[q]) {
             if (p.squeezing == 1) {
-              atomicAdd(&tile_re[d], p.leb_val);
+              S[q] = {p.leb_val, (T)0};
             } else {
-              atomicAdd(&tile_re[d], S.x * p.dw);
-              atomicAdd(&tile_im[d], S.y * p.dw);
+              S[q] = {S[q].x * p.dw, S[q].y * p.dw};      // weight * dw  (ssq_stft.rs:298)
             }
+            l1 += fabs(S[q].x) + fabs(S[q].y);
+          }
+        }
+      }
+      if (p.out_kind == 0) {                       // SSQ_OUT_TX: fixed-point scatter (see header)
+        // every partial sum of this column is bounded by its L1 mass: pick 2^e > L1 and
+        // accumulate round(val * 2^(FRAC-e)) with integer LDS atomics
+        T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t);
+        int e = 0;
+        (void)frexp(tot, &e);
+        if (e < C::EMIN) e = C::EMIN;
+        T scale = ldexp((T)1, C::FRAC - e);
+        T inv_scale = ldexp((T)1, e - C::FRAC);
+        if (!(tot < (T)INFINITY)) {                // NaN/Inf in this frame: the column comes out NaN
+          scale = (T)0;
+          inv_scale = tot - tot;
+        }
+        if (t == 0 && valid) col_scale[fl] = inv_scale;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          if (keep[q]) {
+            const int d = kk[q] * PITCH + fl;
+            atomicAdd(reinterpret_cast<UT*>(&tile_re[d]), (UT)to_fixed<T>(S[q].x * scale));
+            if (p.squeezing != 1) atomicAdd(reinterpret_cast<UT*>(&tile_im[d]), (UT)to_fixed<T>(S[q].y * scale));
           }
         }
       }
@@ -203,12 +281,20 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 
     // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
     cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0;
+    const bool fixed = (p.out_kind == 0);
     for (int i = tid; i < NF * F; i += C::W * 64) {
       const int k = i / F, f = i % F;
       const int o = k * PITCH + f;
-      const cpx<T> val = {tile_re[o], tile_im[o]};
-      tile_re[o] = (T)0;
-      tile_im[o] = (T)0;
+      const IT ire = tile_re[o], iim = tile_im[o];
+      tile_re[o] = 0;
+      tile_im[o] = 0;
+      cpx<T> val;
+      if (fixed) {
+        const T sc = col_scale[f];
+        val = {(T)ire * sc, (T)iim * sc};
+      } else {
+        val = {from_int<T>(ire), from_int<T>(iim)};
+      }
       if (frame0 + f < p.n_frames) og[(long long)k * p.n_frames + f] = val;
     }
     __syncthreads();
