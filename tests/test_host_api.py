@@ -1,0 +1,72 @@
+"""CPU tests of the Python mirror `ssqueeze_rs_amd._rs`: surface, defaults and error behaviour of
+the reference's PyO3 module (rust/src/lib.rs:22-35, src/ssqueeze/_rs.pyi) -- everything that is
+decided before the GPU is touched."""
+import inspect
+
+import numpy as np
+import pytest
+
+from ssqueeze_rs_amd import _rs
+
+
+def test_module_surface_matches_lib_rs():
+    for name in ("hello_from_bin", "stft", "ssq_stft", "cwt", "cwt_simd", "ssq_cwt"):   # lib.rs:25-32
+        assert callable(getattr(_rs, name))
+    assert _rs.hello_from_bin() == "Hello from ssqueeze!"
+    import ssqueeze_rs_amd
+    assert ssqueeze_rs_amd._rs is _rs
+
+
+def _defaults(fn):
+    return {k: v.default for k, v in inspect.signature(fn).parameters.items()
+            if v.default is not inspect.Parameter.empty and not k.startswith("_")}
+
+
+def test_signatures_and_defaults_match_pyo3_signatures():
+    assert list(inspect.signature(_rs.stft).parameters) == ["x", "n_fft", "hop_length", "window", "padtype"]
+    assert _defaults(_rs.stft) == {}                                             # stft.rs:12-19: all required
+    assert _defaults(_rs.ssq_stft) == dict(n_fft=None, win_len=None, hop_len=1, fs=1.0, padtype="reflect",
+                                           squeezing="sum", gamma=None)          # ssq_stft.rs:73
+    cwt_d = dict(wavelet="gmw", scales=None, fs=None, t=None, nv=32, l1_norm=True, derivative=False,
+                 padtype="reflect", rpadded=False, vectorized=True, patience=0)  # cwt.rs:32-45
+    assert _defaults(_rs.cwt) == cwt_d and _defaults(_rs.cwt_simd) == cwt_d
+    assert _defaults(_rs.ssq_cwt) == dict(wavelet="gmw", scales=None, fs=None, t=None, ssq_freqs=None, nv=32,
+                                          padtype="reflect", squeezing="sum", maprange="peak", difftype="trig",
+                                          gamma=None, vectorized=True, flipud=True)   # ssq_cwt.rs:245-260
+    assert list(inspect.signature(_rs.ssq_stft).parameters)[:2] == ["x", "window"]
+
+
+def test_argument_errors_raised_before_any_gpu_work():
+    x = np.sin(np.arange(1000.0))
+    win = np.hanning(256)
+    with pytest.raises(TypeError):
+        _rs.stft(list(x), 256, 64, win, "reflect")               # not an ndarray
+    with pytest.raises(TypeError):
+        _rs.stft(x.astype(np.int64), 256, 64, win, "reflect")    # not float
+    with pytest.raises(TypeError):
+        _rs.stft(x.reshape(10, 10, 10), 256, 64, win, "reflect")
+    with pytest.raises(TypeError):
+        _rs.stft(x, 256.0, 64, win, "reflect")                   # usize argument
+    with pytest.raises(OverflowError):
+        _rs.stft(x, -256, 64, win, "reflect")
+    with pytest.raises(_rs.PanicException):
+        _rs.stft(x, 256, 64, np.hanning(100), "reflect")         # stft.rs:67 rustfft length panic
+    with pytest.raises(_rs.PanicException):
+        _rs.stft(x, 256, 0, win, "reflect")                      # /0
+    with pytest.raises(_rs.PanicException):
+        _rs.stft(x[:0], 256, 64, win, "reflect")                 # usize underflow
+    with pytest.raises(ValueError, match="Window length 300 cannot be greater than n_fft 256"):
+        _rs.ssq_stft(x, np.hanning(300), n_fft=256)              # ssq_stft.rs:96-101
+    with pytest.raises(ValueError):
+        _rs.ssq_stft(x, np.hanning(600))                         # default n_fft = min(N, 512)
+    with pytest.raises(_rs.PanicException):
+        _rs.ssq_stft(x, np.ones(1), n_fft=1)                     # ssq_freqs[1] out of bounds (:273)
+    with pytest.raises(ValueError, match="Time vector must have at least 2 elements"):
+        _rs.cwt(x, t=np.array([0.0]))                            # cwt.rs:68-70
+    with pytest.raises(ValueError):
+        _rs.ssq_cwt(x, t=np.array([0.0]))                        # ssq_cwt.rs:285-287
+    with pytest.raises(TypeError):
+        _rs.ssq_cwt(x, ssq_freqs=np.linspace(1, 2, 8))           # a str in the reference (:268)
+    with pytest.raises(_rs.PanicException):
+        _rs.ssq_cwt(x, scales=np.zeros(0))                       # scales[len-1] (:459)
+    assert not issubclass(_rs.PanicException, Exception)         # like pyo3_runtime.PanicException
