@@ -46,7 +46,7 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
     twre[i] = (double)cosl(ang);
     twim[i] = (double)(-sinl(ang));
     tw[i] = {(T)twre[i], (T)twim[i]};
-    win2[i] = {(T)g[i], (T)(gdfs[i] * pl->alpha)};
+    win2[i] = {(T)(0.5 * g[i]), (T)(0.5 * gdfs[i] * pl->alpha)};   // halved: the unpack then needs no scaling
   }
   std::vector<T> fr((size_t)pl->n_freqs);
   for (int i = 0; i < pl->n_freqs; ++i) fr[i] = (T)pl->ssq_freqs[i];
@@ -93,6 +93,8 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.leb_val = (T)((1.0 / (double)pl->n_freqs) * pl->dw);
   p.f_last = (T)pl->ssq_freqs[pl->n_freqs - 1];
   p.inv_alpha = (T)(1.0 / pl->alpha);
+  p.two_pi_eff = (T)(6.283185307179586 * (pl->fused ? pl->alpha : 1.0));
+  p.leb_unit = (T)(1.0 / (double)pl->n_freqs);
   return p;
 }
 

@@ -16,6 +16,8 @@
 // autosort with in-register radix-16 butterflies and one LDS exchange between passes;
 // for N <= 1024 a frame lives inside one wavefront, so the exchanges need no block
 // barrier.  The N-k partner for the real-pair unpack comes by ds_bpermute, not LDS.
+// The next frame's samples are prefetched into registers before the current frame's FFT.
+//
 // The Tx tile is two planes [n_freqs][F+1] (odd pitch => the per-frame scatter spreads over all
 // 32 banks) that accumulate FIXED POINT: LDS float atomics cost ~3 cycles per LANE on gfx950
 // (187 cycles per wave instruction, measured: tools/ubench/lds_atomics.hip) while integer LDS
@@ -23,6 +25,10 @@
 // scale 2^(FRAC-e) with 2^e > the column's L1 mass, so no partial sum can overflow, the
 // quantisation step (2^-30 resp. 2^-62 of the column's L1 mass) sits below the FFT's own
 // rounding error, and -- integer adds being associative -- the result is bitwise reproducible.
+//
+// The window tables arrive pre-multiplied by 1/2 (so the unpack needs no scaling) and the
+// derivative channel by a power of two alpha (balances the two packed channels); alpha is
+// folded into the 2*pi of the phase transform (StftDev::two_pi_eff).
 #include <type_traits>
 #include "fft_core.h"
 #include "stft_kernels.h"
@@ -40,8 +46,10 @@ struct FusedCfg {
   static constexpr int NF = N / 2 + 1;
   static constexpr int EXCH_ELEMS = N + N / 16;            // +1 element per 16: bank spread
   static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)sizeof(cpx<T>);
+  static constexpr bool WIN_LDS = (sizeof(T) == 4) && (N <= 1024);   // window table in LDS
+  static constexpr int WIN_BYTES = WIN_LDS ? N * (int)sizeof(cpx<T>) : 0;
   static constexpr int LDS_MAX = 160 * 1024;
-  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
+  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - WIN_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
   static constexpr int FT = (sizeof(T) == 4) ? 16 : 8;     // target: >=128-B row segments
   static constexpr int FCAP = (FT < FMAX) ? FT : FMAX;
   static constexpr int F = (FIF >= FT) ? FIF : (FCAP / FIF) * FIF;
@@ -52,14 +60,13 @@ struct FusedCfg {
   using UT = std::conditional_t<sizeof(T) == 4, unsigned int, unsigned long long>;
   static constexpr int FRAC = (sizeof(T) == 4) ? 30 : 62;      // fixed-point fraction bits
   static constexpr int EMIN = (sizeof(T) == 4) ? -90 : -960;   // keeps 2^(FRAC-e) finite
-  static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES;
+  static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES + WIN_BYTES;
   static constexpr int NP = num_passes(LOGN);
   static constexpr bool TW_REGS = (sizeof(T) == 4);
-  static constexpr bool WIN_REGS = (sizeof(T) == 4) && (N <= 1024);
+  static constexpr int ITERS = F / FIF;                    // frame groups per tile
   static_assert(F >= FIF && F % FIF == 0, "tile must hold whole in-flight groups");
   static_assert(LDS_BYTES <= LDS_MAX, "LDS budget");
 };
-
 
 // bit casts between T and its integer twin (debug outputs travel through the integer tile)
 template <typename T>
@@ -78,12 +85,33 @@ __device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> to
   else return __double2ll_rn(v);
 }
 
-// sum of `v` over the L lanes that hold one frame (all of them get the total)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// Sum of `v` over the L lanes that hold one frame; every lane of the frame gets the SAME value
+// (each step adds a lane and its exchange partner, and fp addition commutes).
 template <typename T, int L, bool MULTIWAVE>
 __device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
   constexpr int LW = (L < 64) ? L : 64;
+  if constexpr (sizeof(T) == 4) {
+    if (LW >= 2) v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    if (LW >= 4) v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    if (LW >= 8) v += dpp_mov<0x141>(v);      // row_half_mirror
+    if (LW >= 16) v += dpp_mov<0x140>(v);     // row_mirror
+    if (LW >= 32) {
+      const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+      const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+      const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+      const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+      if (LW == 32) v = (lane < 32) ? (r0 + r1) : (r2 + r3);
+      else v = (r0 + r1) + (r2 + r3);
+    }
+  } else {
 #pragma unroll
-  for (int m = LW / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    for (int m = LW / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+  }
   if constexpr (MULTIWAVE) {
     // a frame spans L/64 waves: combine the wave totals through the frame's (idle) exchange row
     __syncthreads();
@@ -98,7 +126,51 @@ __device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
   return v;
 }
 
+// one unit of work of a lane: frame (tile, it) -> where its samples are
+template <typename T>
+struct FrameItem {
+  const T* xs;          // signal base
+  long long pos0;       // original-signal index of this lane's element q = 0
+  long long sig;
+  int frame0;           // first frame of the tile
+  int fl;               // frame index inside the tile
+  bool valid;           // frame < n_frames
+  bool interior;        // whole tile needs no padding
+};
+
 template <typename T, int LOGN>
+__device__ __forceinline__ FrameItem<T> decode_item(const StftDev<T>& p, long long tile, int it, int slot, int t) {
+  using C = FusedCfg<T, LOGN>;
+  FrameItem<T> w;
+  w.sig = tile / p.tiles_per_signal;
+  w.frame0 = (int)(tile % p.tiles_per_signal) * C::F;
+  w.fl = it * C::FIF + slot;
+  const int frame = w.frame0 + w.fl;
+  w.valid = frame < p.n_frames;
+  w.xs = p.x + w.sig * p.n_signal;
+  const long long first = (long long)w.frame0 * p.hop - p.pad_left;
+  w.interior = (first >= 0) && (first + (long long)(C::F - 1) * p.hop + C::N <= p.n_signal) &&
+               (w.frame0 + C::F <= p.n_frames);
+  w.pos0 = (long long)frame * p.hop - p.pad_left + t;
+  return w;
+}
+
+template <typename T, int LOGN>
+__device__ __forceinline__ void load_samples(const StftDev<T>& p, const FrameItem<T>& w, T (&xv)[16]) {
+  constexpr int L = FusedCfg<T, LOGN>::L;
+  if (w.interior) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      xv[q] = w.valid ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+  }
+}
+
+// TXONLY = true : out_kind == SSQ_OUT_TX (the hot path: branch-free epilogue)
+// TXONLY = false: SSQ_OUT_SX / DSX / WK  (stft and the test hooks)
+template <typename T, int LOGN, bool TXONLY>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
@@ -110,6 +182,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   IT* tile_im = tile_re + C::PLANE;
   T* col_scale = reinterpret_cast<T*>(tile_im + C::PLANE);     // [F] 2^(e-FRAC) per column
   cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES);
+  cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES + C::EXCH_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,162 +215,164 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       }
     }
   }
-  cpx<T> winr[16];
-  if constexpr (C::WIN_REGS) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) winr[q] = p.win2[t + L * q];
+  if constexpr (C::WIN_LDS) {
+    for (int i = tid; i < N; i += C::W * 64) win_lds[i] = p.win2[i];
   }
-
   // zero the tile once; afterwards the read-out pass re-zeroes what it reads
   for (int i = tid; i < 2 * C::PLANE; i += C::W * 64) tile_re[i] = 0;
   __syncthreads();
 
-  const T half = (T)0.5;
-  const T dhalf = (T)0.5 * p.inv_alpha;
-  for (long long tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
-    const long long sig = tile / p.tiles_per_signal;
-    const int frame0 = (int)(tile % p.tiles_per_signal) * F;
-    const T* __restrict__ xs = p.x + sig * p.n_signal;
-    const long long first = (long long)frame0 * p.hop - p.pad_left;
-    const bool interior = (first >= 0) && (first + (long long)(F - 1) * p.hop + N <= p.n_signal) &&
-                          (frame0 + F <= p.n_frames);
+  long long tile = blockIdx.x;
+  int it = 0;
+  if (tile >= p.total_tiles) return;
+  FrameItem<T> cur = decode_item<T, LOGN>(p, tile, it, slot, t);
+  T xn[16];
+  load_samples<T, LOGN>(p, cur, xn);
 
 #pragma unroll 1
-    for (int it = 0; it < F / C::FIF; ++it) {
-      const int fl = it * C::FIF + slot;          // frame index inside the tile
-      const int frame = frame0 + fl;
-      const bool valid = frame < p.n_frames;
-      const long long pos0 = (long long)frame * p.hop - p.pad_left + t;
+  while (true) {
+    // ---- window multiply; then prefetch the next frame's samples behind this frame's FFT ----
+    cpx<T> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : p.win2[t + L * q];
+      v[q] = {xn[q] * wq.x, xn[q] * wq.y};
+    }
+    long long ntile = tile;
+    int nit = it + 1;
+    if (nit == C::ITERS) {
+      nit = 0;
+      ntile += gridDim.x;
+    }
+    const bool has_next = ntile < p.total_tiles;
+    FrameItem<T> nxt = cur;
+    if (has_next) {
+      nxt = decode_item<T, LOGN>(p, ntile, nit, slot, t);
+      load_samples<T, LOGN>(p, nxt, xn);
+    }
 
-      cpx<T> v[16];
-      if (interior) {
+    fft_pass<T, LOGN, 0, false, C::TW_REGS, MULTIWAVE>(v, exch, twr, p.tw, t);
+    // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
+
+    // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
+    cpx<T> zp[9];
+    if constexpr (!MULTIWAVE) {
+      const int src = (lane - t) + ((L - t) & (L - 1));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const T xv = xs[pos0 + L * q];
-          const cpx<T> wq = C::WIN_REGS ? winr[q] : p.win2[t + L * q];
-          v[q] = {xv * wq.x, xv * wq.y};
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const T xv = valid ? load_padded(xs, pos0 + L * q, p.n_signal, p.padtype) : (T)0;
-          const cpx<T> wq = C::WIN_REGS ? winr[q] : p.win2[t + L * q];
-          v[q] = {xv * wq.x, xv * wq.y};
-        }
+      for (int q = 0; q < 8; ++q) {
+        cpx<T> r;
+        r.x = __shfl(v[15 - q].x, src);
+        r.y = __shfl(v[15 - q].y, src);
+        if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
+        zp[q] = r;
       }
-
-      fft_pass<T, LOGN, 0, false, C::TW_REGS, MULTIWAVE>(v, exch, twr, p.tw, t);
-      // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
-
-      // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
-      cpx<T> zp[9];
-      if constexpr (!MULTIWAVE) {
-        const int src = (lane - t) + ((L - t) & (L - 1));
+      zp[8] = v[8];                              // k = N/2 pairs with itself (t == 0 only)
+    } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          cpx<T> r;
-          r.x = __shfl(v[15 - q].x, src);
-          r.y = __shfl(v[15 - q].y, src);
-          if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
-          zp[q] = r;
-        }
-        zp[8] = v[8];                              // k = N/2 pairs with itself (t == 0 only)
-      } else {
+      for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[q];
+      __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[q];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int k = t + L * q;
-          zp[q] = exch[exch_phys((N - k) & (N - 1))];
-        }
-        zp[8] = v[8];
-        __syncthreads();
+      for (int q = 0; q < 8; ++q) {
+        const int k = t + L * q;
+        zp[q] = exch[exch_phys((N - k) & (N - 1))];
       }
+      zp[8] = v[8];
+      __syncthreads();
+    }
 
-      // ---- unpack, phase transform, reassignment ----
-      cpx<T> S[9];
-      int kk[9];
-      bool keep[9];
-      T l1 = (T)0;                                // this lane's share of the column's L1 mass (x dw)
+    const int fl = cur.fl;
+    if constexpr (TXONLY) {
+      // ---- unpack, phase transform, bin index: branch-free; skipped bins contribute 0 ----
+      cpx<T> cv[9];
+      int dst[9];
+      T l1 = (T)0;
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        keep[q] = false;
-        kk[q] = 0;
-        if (q == 8 && t != 0) break;
         const int k = t + L * q;
         const cpx<T> zk = v[q], zn = zp[q];
-        S[q] = {half * (zk.x + zn.x), half * (zk.y - zn.y)};
-        const cpx<T> dS = {dhalf * (zk.y + zn.y), dhalf * (zn.x - zk.x)};
-        if (!valid) continue;
+        const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+        const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
+        T w;
+        int kk;
+        bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+        keep = keep && cur.valid && (q < 8 || t == 0);
+        cpx<T> c = (p.squeezing == 1) ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
+        c.x = keep ? c.x : (T)0;
+        c.y = keep ? c.y : (T)0;
+        cv[q] = c;
+        dst[q] = (keep ? kk : 0) * PITCH + fl;
+        l1 += fabs(c.x) + fabs(c.y);
+      }
+      // fixed-point scatter: every partial sum of this column is bounded by its L1 mass dw*sum|c|;
+      // pick 2^e above it and accumulate round(c * dw * 2^(FRAC-e)) with integer LDS atomics
+      const T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t) * p.dw;
+      int e = 0;
+      (void)frexp(tot, &e);
+      if (e < C::EMIN) e = C::EMIN;
+      T scale = ldexp(p.dw, C::FRAC - e);          // weight * dw  (ssq_stft.rs:298), then fixed point
+      T inv_scale = ldexp((T)1, e - C::FRAC);
+      if (!(tot < (T)INFINITY)) {                  // NaN/Inf in this frame: the column comes out NaN
+        scale = (T)0;
+        inv_scale = tot - tot;
+      }
+      if (t == 0 && cur.valid) col_scale[fl] = inv_scale;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (q == 8 && t != 0) break;
+        atomicAdd(reinterpret_cast<UT*>(&tile_re[dst[q]]), (UT)to_fixed<T>(cv[q].x * scale));
+        if (p.squeezing != 1) atomicAdd(reinterpret_cast<UT*>(&tile_im[dst[q]]), (UT)to_fixed<T>(cv[q].y * scale));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (q == 8 && t != 0) break;
+        if (!cur.valid) continue;
+        const int k = t + L * q;
+        const cpx<T> zk = v[q], zn = zp[q];
+        const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+        const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};
         const int o = k * PITCH + fl;
         if (p.out_kind == 1) {                     // SSQ_OUT_SX
-          tile_re[o] = as_int<T>(S[q].x);
-          tile_im[o] = as_int<T>(S[q].y);
+          tile_re[o] = as_int<T>(S.x);
+          tile_im[o] = as_int<T>(S.y);
         } else if (p.out_kind == 2) {              // SSQ_OUT_DSX
-          tile_re[o] = as_int<T>(dS.x);
-          tile_im[o] = as_int<T>(dS.y);
-        } else {
+          tile_re[o] = as_int<T>(dS.x * p.inv_alpha);
+          tile_im[o] = as_int<T>(dS.y * p.inv_alpha);
+        } else {                                   // SSQ_OUT_WK
           T w;
-          keep[q] = phase_bin<T>(p, k, S[q], dS, w, kk[q]);
-          if (p.out_kind == 3) {                   // SSQ_OUT_WK
-            tile_re[o] = as_int<T>(w);
-            tile_im[o] = as_int<T>(keep[q] ? (T)kk[q] : (T)-1);
-          } else if (keep[q]) {
-            if (p.squeezing == 1) {
-              S[q] = {p.leb_val, (T)0};
-            } else {
-              S[q] = {S[q].x * p.dw, S[q].y * p.dw};      // weight * dw  (ssq_stft.rs:298)
-            }
-            l1 += fabs(S[q].x) + fabs(S[q].y);
-          }
-        }
-      }
-      if (p.out_kind == 0) {                       // SSQ_OUT_TX: fixed-point scatter (see header)
-        // every partial sum of this column is bounded by its L1 mass: pick 2^e > L1 and
-        // accumulate round(val * 2^(FRAC-e)) with integer LDS atomics
-        T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t);
-        int e = 0;
-        (void)frexp(tot, &e);
-        if (e < C::EMIN) e = C::EMIN;
-        T scale = ldexp((T)1, C::FRAC - e);
-        T inv_scale = ldexp((T)1, e - C::FRAC);
-        if (!(tot < (T)INFINITY)) {                // NaN/Inf in this frame: the column comes out NaN
-          scale = (T)0;
-          inv_scale = tot - tot;
-        }
-        if (t == 0 && valid) col_scale[fl] = inv_scale;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          if (keep[q]) {
-            const int d = kk[q] * PITCH + fl;
-            atomicAdd(reinterpret_cast<UT*>(&tile_re[d]), (UT)to_fixed<T>(S[q].x * scale));
-            if (p.squeezing != 1) atomicAdd(reinterpret_cast<UT*>(&tile_im[d]), (UT)to_fixed<T>(S[q].y * scale));
-          }
+          int kk;
+          const bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+          tile_re[o] = as_int<T>(w);
+          tile_im[o] = as_int<T>(keep ? (T)kk : (T)-1);
         }
       }
     }
-    __syncthreads();
 
-    // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
-    cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0;
-    const bool fixed = (p.out_kind == 0);
-    for (int i = tid; i < NF * F; i += C::W * 64) {
-      const int k = i / F, f = i % F;
-      const int o = k * PITCH + f;
-      const IT ire = tile_re[o], iim = tile_im[o];
-      tile_re[o] = 0;
-      tile_im[o] = 0;
-      cpx<T> val;
-      if (fixed) {
-        const T sc = col_scale[f];
-        val = {(T)ire * sc, (T)iim * sc};
-      } else {
-        val = {from_int<T>(ire), from_int<T>(iim)};
+    if (it == C::ITERS - 1) {
+      __syncthreads();
+      // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
+      cpx<T>* __restrict__ og = p.out + cur.sig * (long long)NF * p.n_frames + cur.frame0;
+      for (int i = tid; i < NF * F; i += C::W * 64) {
+        const int k = i / F, f = i % F;
+        const int o = k * PITCH + f;
+        const IT ire = tile_re[o], iim = tile_im[o];
+        tile_re[o] = 0;
+        tile_im[o] = 0;
+        cpx<T> val;
+        if constexpr (TXONLY) {
+          const T sc = col_scale[f];
+          val = {(T)ire * sc, (T)iim * sc};
+        } else {
+          val = {from_int<T>(ire), from_int<T>(iim)};
+        }
+        if (cur.frame0 + f < p.n_frames) og[(long long)k * p.n_frames + f] = val;
       }
-      if (frame0 + f < p.n_frames) og[(long long)k * p.n_frames + f] = val;
+      __syncthreads();
     }
-    __syncthreads();
+    if (!has_next) break;
+    tile = ntile;
+    it = nit;
+    cur = nxt;
   }
 }
 
@@ -316,7 +391,10 @@ static hipError_t launch_one(const StftDev<T>& p, int cu_count, hipStream_t stre
   long long blocks = (long long)cu_count * per_cu;
   if (blocks > p.total_tiles) blocks = p.total_tiles;
   if (blocks < 1) return hipSuccess;
-  hipLaunchKernelGGL((stft_fused_kernel<T, LOGN>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
+  if (p.out_kind == 0)
+    hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
+  else
+    hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
   return hipGetLastError();
 }
 

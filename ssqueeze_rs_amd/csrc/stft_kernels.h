@@ -10,7 +10,7 @@ struct StftDev {
   const T* x;              // [batch][n_signal]
   cpx<T>* out;             // [batch][n_freqs][n_frames]
   const cpx<T>* tw;        // W_N^i = exp(-2*pi*i*i/N), i in [0, N)
-  const cpx<T>* win2;      // (g[n], g'[n]*fs*alpha): alpha = power of two balancing the two packed channels
+  const cpx<T>* win2;      // fused kernel: (g[n]/2, g'[n]*fs*alpha/2), alpha = power of two balancing the channels
   const T* ssq_freqs;      // [n_freqs] reference expression (ssq_stft.rs:50), exact fix-up table
   long long n_signal;
   long long total_tiles;
@@ -29,6 +29,8 @@ struct StftDev {
   T leb_val;               // (1/n_freqs)*dw               (ssq_stft.rs:294,298)
   T f_last;                // ssq_freqs[n_freqs-1]
   T inv_alpha;             // dSx = unpacked imaginary channel * inv_alpha (exact: power of two)
+  T two_pi_eff;            // 2*pi*alpha when phase_bin is fed alpha*dSx (fused), 2*pi otherwise
+  T leb_unit;              // 1/n_freqs weight of "lebesgue" (ssq_stft.rs:294), without the dw factor
 };
 
 // fused LDS-tile kernel (stft_fused.hip): 64 <= n_fft <= 4096, power of two
@@ -60,13 +62,13 @@ hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx
 //   w  = |Sfs[i] - Im(dSx/Sx)/(2*pi)|           ssq_stft.rs:23-33
 //   kk = first argmin_idx |w - ssq_freqs[idx]|   ssq_stft.rs:280-289
 // Returns false when the bin is skipped (|Sx| < gamma or w infinite, :23,:278).
-// `dS` is the true dSx (already multiplied by inv_alpha).
+// `dS` is dSx times the factor folded into p.two_pi_eff (alpha in the fused kernel, 1 otherwise).
 // ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
   const T den = S.x * S.x + S.y * S.y;
   const T num = dS.y * S.x - dS.x * S.y;
-  const T two_pi = (T)6.283185307179586;
+  const T two_pi = p.two_pi_eff;                    // 6.283185307179586 (ssq_stft.rs:32) [* alpha]
   T pd;
   if constexpr (sizeof(T) == 4) {
     pd = num * __builtin_amdgcn_rcpf(den * two_pi);
