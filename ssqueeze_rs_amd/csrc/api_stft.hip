@@ -2,6 +2,7 @@
 // Replaces the PyO3 functions `stft` (rust/src/spectral/stft.rs:12-95) and `ssq_stft`
 // (rust/src/spectral/ssq_stft.rs:72-313).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -95,6 +96,10 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.inv_alpha = (T)(1.0 / pl->alpha);
   p.two_pi_eff = (T)(6.283185307179586 * (pl->fused ? pl->alpha : 1.0));
   p.leb_unit = (T)(1.0 / (double)pl->n_freqs);
+  {
+    const char* ab = std::getenv("SSQ_ABLATE");
+    p.ablate = ab ? std::atoi(ab) : 0;
+  }
   return p;
 }
 

@@ -30,12 +30,11 @@ __device__ __forceinline__ void butterflies(cpx<T> (&v)[16], std::integer_sequen
   (dft_strided<INV, R, Bs, NB>(v), ...);
 }
 
-// One Stockham pass P of the 16-elements-per-lane FFT (see ssq_common.h pass tables).
-template <typename T, int LOGN, int P, bool INV, bool TW_REGS, bool MULTIWAVE>
-__device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cpx<T> (&twr)[3][16],
-                                         const cpx<T>* __restrict__ tw_tab, int t) {
+// Twiddle multiply (P > 0) + in-register butterflies of Stockham pass P (see ssq_common.h pass tables).
+template <typename T, int LOGN, int P, bool INV, bool TW_REGS>
+__device__ __forceinline__ void fft_compute(cpx<T> (&v)[16], const cpx<T> (&twr)[3][16],
+                                            const cpx<T>* __restrict__ tw_tab, int t) {
   constexpr int N = 1 << LOGN, L = N / 16;
-  constexpr int NP = num_passes(LOGN);
   constexpr int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
   if constexpr (P > 0) {
 #pragma unroll
@@ -55,20 +54,50 @@ __device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cp
     }
   }
   butterflies<INV, R, NB>(v, std::make_integer_sequence<int, NB>{});
-  if constexpr (P < NP - 1) {
+}
+
+// LDS exchange after pass P: lane t writes its butterfly outputs at their Stockham positions and
+// reads back elements t + L*q.  The DS unit executes a wave's operations in order, so a second
+// frame may reuse the same row right behind this one without waiting.
+template <typename T, int LOGN, int P, bool MULTIWAVE>
+__device__ __forceinline__ void fft_exchange(cpx<T> (&v)[16], cpx<T>* exch, int t) {
+  constexpr int N = 1 << LOGN, L = N / 16;
+  constexpr int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int j = t + L * b;
-      const int k = j & (NS - 1);
-      const int base = (j - k) * R + k;
+  for (int b = 0; b < NB; ++b) {
+    const int j = t + L * b;
+    const int k = j & (NS - 1);
+    const int base = (j - k) * R + k;
 #pragma unroll
-      for (int u = 0; u < R; ++u) exch[exch_phys(base + u * NS)] = v[b + u * NB];
-    }
-    frame_sync<MULTIWAVE>();
+    for (int u = 0; u < R; ++u) exch[exch_phys(base + u * NS)] = v[b + u * NB];
+  }
+  frame_sync<MULTIWAVE>();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = exch[exch_phys(t + L * q)];
-    frame_sync<MULTIWAVE>();
+  for (int q = 0; q < 16; ++q) v[q] = exch[exch_phys(t + L * q)];
+  frame_sync<MULTIWAVE>();
+}
+
+// The whole transform of one frame: passes P .. NP-1.
+template <typename T, int LOGN, int P, bool INV, bool TW_REGS, bool MULTIWAVE>
+__device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cpx<T> (&twr)[3][16],
+                                         const cpx<T>* __restrict__ tw_tab, int t) {
+  fft_compute<T, LOGN, P, INV, TW_REGS>(v, twr, tw_tab, t);
+  if constexpr (P < num_passes(LOGN) - 1) {
+    fft_exchange<T, LOGN, P, MULTIWAVE>(v, exch, t);
     fft_pass<T, LOGN, P + 1, INV, TW_REGS, MULTIWAVE>(v, exch, twr, tw_tab, t);
+  }
+}
+
+// Two frames of one wave, staggered: while one frame's exchange is in flight the other computes.
+template <typename T, int LOGN, int P, bool INV, bool TW_REGS>
+__device__ __forceinline__ void fft_pass_pair(cpx<T> (&a)[16], cpx<T> (&b)[16], cpx<T>* exch,
+                                              const cpx<T> (&twr)[3][16], const cpx<T>* __restrict__ tw_tab, int t) {
+  fft_compute<T, LOGN, P, INV, TW_REGS>(a, twr, tw_tab, t);
+  if constexpr (P < num_passes(LOGN) - 1) fft_exchange<T, LOGN, P, false>(a, exch, t);
+  fft_compute<T, LOGN, P, INV, TW_REGS>(b, twr, tw_tab, t);
+  if constexpr (P < num_passes(LOGN) - 1) {
+    fft_exchange<T, LOGN, P, false>(b, exch, t);
+    fft_pass_pair<T, LOGN, P + 1, INV, TW_REGS>(a, b, exch, twr, tw_tab, t);
   }
 }
 

@@ -48,8 +48,9 @@ struct FusedCfg {
   static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)sizeof(cpx<T>);
   static constexpr bool WIN_LDS = (sizeof(T) == 4) && (N <= 1024);   // window table in LDS
   static constexpr int WIN_BYTES = WIN_LDS ? N * (int)sizeof(cpx<T>) : 0;
+  static constexpr int TWL_BYTES = WIN_LDS ? N * (int)sizeof(cpx<T>) : 0;   // W_N table in LDS (paired-frame kernels)
   static constexpr int LDS_MAX = 160 * 1024;
-  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - WIN_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
+  static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - WIN_BYTES - TWL_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
   static constexpr int FT = (sizeof(T) == 4) ? 16 : 8;     // target: >=128-B row segments
   static constexpr int FCAP = (FT < FMAX) ? FT : FMAX;
   static constexpr int F = (FIF >= FT) ? FIF : (FCAP / FIF) * FIF;
@@ -60,7 +61,7 @@ struct FusedCfg {
   using UT = std::conditional_t<sizeof(T) == 4, unsigned int, unsigned long long>;
   static constexpr int FRAC = (sizeof(T) == 4) ? 30 : 62;      // fixed-point fraction bits
   static constexpr int EMIN = (sizeof(T) == 4) ? -90 : -960;   // keeps 2^(FRAC-e) finite
-  static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES + WIN_BYTES;
+  static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES + WIN_BYTES + TWL_BYTES;
   static constexpr int NP = num_passes(LOGN);
   static constexpr bool TW_REGS = (sizeof(T) == 4);
   static constexpr int ITERS = F / FIF;                    // frame groups per tile
@@ -126,39 +127,53 @@ __device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
   return v;
 }
 
-// one unit of work of a lane: frame (tile, it) -> where its samples are
+// one unit of work of a lane: frame `fl` of tile (sig, ft) -> where its samples are
 template <typename T>
 struct FrameItem {
   const T* xs;          // signal base
   long long pos0;       // original-signal index of this lane's element q = 0
-  long long sig;
-  int frame0;           // first frame of the tile
   int fl;               // frame index inside the tile
   bool valid;           // frame < n_frames
-  bool interior;        // whole tile needs no padding
+};
+
+// a tile of F frames of one signal
+struct TileItem {
+  long long sig;
+  int ft;               // tile index inside the signal
+  int frame0;           // first frame
+  bool interior;        // no frame of the tile needs padding
 };
 
 template <typename T, int LOGN>
-__device__ __forceinline__ FrameItem<T> decode_item(const StftDev<T>& p, long long tile, int it, int slot, int t) {
+__device__ __forceinline__ TileItem make_tile(const StftDev<T>& p, long long sig, int ft) {
   using C = FusedCfg<T, LOGN>;
-  FrameItem<T> w;
-  w.sig = tile / p.tiles_per_signal;
-  w.frame0 = (int)(tile % p.tiles_per_signal) * C::F;
-  w.fl = it * C::FIF + slot;
-  const int frame = w.frame0 + w.fl;
-  w.valid = frame < p.n_frames;
-  w.xs = p.x + w.sig * p.n_signal;
+  TileItem w;
+  w.sig = sig;
+  w.ft = ft;
+  w.frame0 = ft * C::F;
   const long long first = (long long)w.frame0 * p.hop - p.pad_left;
   w.interior = (first >= 0) && (first + (long long)(C::F - 1) * p.hop + C::N <= p.n_signal) &&
                (w.frame0 + C::F <= p.n_frames);
+  return w;
+}
+
+template <typename T, int LOGN>
+__device__ __forceinline__ FrameItem<T> make_frame(const StftDev<T>& p, const TileItem& tl, int it, int slot, int t) {
+  using C = FusedCfg<T, LOGN>;
+  FrameItem<T> w;
+  w.fl = it * C::FIF + slot;
+  const int frame = tl.frame0 + w.fl;
+  w.valid = frame < p.n_frames;
+  w.xs = p.x + tl.sig * p.n_signal;
   w.pos0 = (long long)frame * p.hop - p.pad_left + t;
   return w;
 }
 
 template <typename T, int LOGN>
-__device__ __forceinline__ void load_samples(const StftDev<T>& p, const FrameItem<T>& w, T (&xv)[16]) {
+__device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem& tl, const FrameItem<T>& w,
+                                             T (&xv)[16]) {
   constexpr int L = FusedCfg<T, LOGN>::L;
-  if (w.interior) {
+  if (tl.interior) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
   } else {
@@ -168,13 +183,26 @@ __device__ __forceinline__ void load_samples(const StftDev<T>& p, const FrameIte
   }
 }
 
-// TXONLY = true : out_kind == SSQ_OUT_TX (the hot path: branch-free epilogue)
+#ifdef SSQ_ABLATE_HOOKS
+#define SSQ_ABL(mask) (p.ablate & (mask))       // timing experiments (tools/ablate.sh); results are wrong
+#else
+#define SSQ_ABL(mask) false
+#endif
+
+// TXONLY = true : out_kind == SSQ_OUT_TX (the hot path: branch-free epilogue; at n_fft = 1024 fp32
+//                 a wave runs its two frames of a tile staggered, so one frame's LDS round trips
+//                 hide behind the other frame's arithmetic)
 // TXONLY = false: SSQ_OUT_SX / DSX / WK  (stft and the test hooks)
 template <typename T, int LOGN, bool TXONLY>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
   constexpr bool MULTIWAVE = (C::WPF > 1);
+  // Staggering a wave's two frames (fft_pass_pair) measured SLOWER here (4.77 vs 3.56 ms): the second
+  // frame's registers push the kernel into scratch.  Kept behind this switch for the next round.
+  constexpr bool PAIR = false && TXONLY && !MULTIWAVE && (sizeof(T) == 4) && (C::ITERS % 2 == 0);
+  constexpr int NFW = PAIR ? 2 : 1;              // frames a wave works on together
+  constexpr int NG = C::ITERS / NFW;             // such groups per tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS_BYTES];
   using IT = typename C::IT;                     // integer twin of T: the tile accumulates fixed point
   using UT = typename C::UT;
@@ -183,6 +211,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   T* col_scale = reinterpret_cast<T*>(tile_im + C::PLANE);     // [F] 2^(e-FRAC) per column
   cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES);
   cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES + C::EXCH_BYTES);
+  cpx<T>* tw_lds = reinterpret_cast<cpx<T>*>(smem + C::TILE_BYTES + C::EXCH_BYTES + C::WIN_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -198,8 +227,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   cpx<T>* exch = exch_all + slot * C::EXCH_ELEMS;
 
   // ---- per-lane constants, live across all tiles this block processes ----
+  constexpr bool TW_REGS = C::TW_REGS && !PAIR;   // paired frames: registers go to the second frame, twiddles to LDS
   cpx<T> twr[3][16];
-  if constexpr (C::TW_REGS) {
+  if constexpr (TW_REGS) {
 #pragma unroll
     for (int P = 1; P < C::NP; ++P) {
       const int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
@@ -218,140 +248,173 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   if constexpr (C::WIN_LDS) {
     for (int i = tid; i < N; i += C::W * 64) win_lds[i] = p.win2[i];
   }
+  if constexpr (PAIR) {
+    for (int i = tid; i < N; i += C::W * 64) tw_lds[i] = p.tw[i];
+  }
+  const cpx<T>* tw_src = PAIR ? tw_lds : p.tw;
   // zero the tile once; afterwards the read-out pass re-zeroes what it reads
   for (int i = tid; i < 2 * C::PLANE; i += C::W * 64) tile_re[i] = 0;
   __syncthreads();
 
-  long long tile = blockIdx.x;
-  int it = 0;
-  if (tile >= p.total_tiles) return;
-  FrameItem<T> cur = decode_item<T, LOGN>(p, tile, it, slot, t);
-  T xn[16];
-  load_samples<T, LOGN>(p, cur, xn);
+  if ((long long)blockIdx.x >= p.total_tiles) return;
+  // (sig, ft) advance by gridDim.x tiles per step without a 64-bit division per frame
+  TileItem tl = make_tile<T, LOGN>(p, (long long)(blockIdx.x / (unsigned)p.tiles_per_signal),
+                                   (int)(blockIdx.x % (unsigned)p.tiles_per_signal));
+  int ig = 0;
+  FrameItem<T> cur[NFW];
+  T xn[NFW][16];
+#pragma unroll
+  for (int f = 0; f < NFW; ++f) {
+    cur[f] = make_frame<T, LOGN>(p, tl, ig * NFW + f, slot, t);
+    load_samples<T, LOGN>(p, tl, cur[f], xn[f]);
+  }
+  const long long n_sig = p.total_tiles / p.tiles_per_signal;
 
 #pragma unroll 1
   while (true) {
-    // ---- window multiply; then prefetch the next frame's samples behind this frame's FFT ----
-    cpx<T> v[16];
+    // ---- window multiply; then prefetch the next frames' samples behind this group's FFTs ----
+    cpx<T> v[NFW][16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : p.win2[t + L * q];
-      v[q] = {xn[q] * wq.x, xn[q] * wq.y};
+#pragma unroll
+      for (int f = 0; f < NFW; ++f) v[f][q] = {xn[f][q] * wq.x, xn[f][q] * wq.y};
     }
-    long long ntile = tile;
-    int nit = it + 1;
-    if (nit == C::ITERS) {
-      nit = 0;
-      ntile += gridDim.x;
+    TileItem ntl = tl;
+    int nig = ig + 1;
+    if (nig == NG) {
+      nig = 0;
+      long long ns = tl.sig;
+      int nft = tl.ft + (int)gridDim.x;
+      while (nft >= p.tiles_per_signal) {
+        nft -= p.tiles_per_signal;
+        ++ns;
+      }
+      ntl = make_tile<T, LOGN>(p, ns, nft);
     }
-    const bool has_next = ntile < p.total_tiles;
-    FrameItem<T> nxt = cur;
-    if (has_next) {
-      nxt = decode_item<T, LOGN>(p, ntile, nit, slot, t);
-      load_samples<T, LOGN>(p, nxt, xn);
+    const bool has_next = ntl.sig < n_sig;
+    FrameItem<T> nxt[NFW];
+#pragma unroll
+    for (int f = 0; f < NFW; ++f) {
+      nxt[f] = cur[f];
+      if (has_next) {
+        nxt[f] = make_frame<T, LOGN>(p, ntl, nig * NFW + f, slot, t);
+        if (!SSQ_ABL(1)) load_samples<T, LOGN>(p, ntl, nxt[f], xn[f]);
+      }
     }
 
-    fft_pass<T, LOGN, 0, false, C::TW_REGS, MULTIWAVE>(v, exch, twr, p.tw, t);
+    if (!SSQ_ABL(2)) {
+      if constexpr (PAIR) fft_pass_pair<T, LOGN, 0, false, false>(v[0], v[1], exch, twr, tw_src, t);
+      else fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
+    }
     // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
 
     // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
-    cpx<T> zp[9];
-    if constexpr (!MULTIWAVE) {
-      const int src = (lane - t) + ((L - t) & (L - 1));
+    cpx<T> zp[NFW][9];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        cpx<T> r;
-        r.x = __shfl(v[15 - q].x, src);
-        r.y = __shfl(v[15 - q].y, src);
-        if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
-        zp[q] = r;
+    for (int f = 0; f < NFW; ++f) {
+      if constexpr (!MULTIWAVE) {
+        const int src = (lane - t) + ((L - t) & (L - 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          cpx<T> r;
+          r.x = __shfl(v[f][15 - q].x, src);
+          r.y = __shfl(v[f][15 - q].y, src);
+          if (t == 0) r = (q == 0) ? v[f][0] : v[f][16 - q];
+          zp[f][q] = r;
+        }
+        zp[f][8] = v[f][8];                      // k = N/2 pairs with itself (t == 0 only)
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[f][q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = t + L * q;
+          zp[f][q] = exch[exch_phys((N - k) & (N - 1))];
+        }
+        zp[f][8] = v[f][8];
+        __syncthreads();
       }
-      zp[8] = v[8];                              // k = N/2 pairs with itself (t == 0 only)
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[q];
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = t + L * q;
-        zp[q] = exch[exch_phys((N - k) & (N - 1))];
-      }
-      zp[8] = v[8];
-      __syncthreads();
     }
 
-    const int fl = cur.fl;
-    if constexpr (TXONLY) {
-      // ---- unpack, phase transform, bin index: branch-free; skipped bins contribute 0 ----
-      cpx<T> cv[9];
-      int dst[9];
-      T l1 = (T)0;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int k = t + L * q;
-        const cpx<T> zk = v[q], zn = zp[q];
-        const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
-        const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
-        T w;
-        int kk;
-        bool keep = phase_bin<T>(p, k, S, dS, w, kk);
-        keep = keep && cur.valid && (q < 8 || t == 0);
-        cpx<T> c = (p.squeezing == 1) ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
-        c.x = keep ? c.x : (T)0;
-        c.y = keep ? c.y : (T)0;
-        cv[q] = c;
-        dst[q] = (keep ? kk : 0) * PITCH + fl;
-        l1 += fabs(c.x) + fabs(c.y);
-      }
-      // fixed-point scatter: every partial sum of this column is bounded by its L1 mass dw*sum|c|;
-      // pick 2^e above it and accumulate round(c * dw * 2^(FRAC-e)) with integer LDS atomics
-      const T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t) * p.dw;
-      int e = 0;
-      (void)frexp(tot, &e);
-      if (e < C::EMIN) e = C::EMIN;
-      T scale = ldexp(p.dw, C::FRAC - e);          // weight * dw  (ssq_stft.rs:298), then fixed point
-      T inv_scale = ldexp((T)1, e - C::FRAC);
-      if (!(tot < (T)INFINITY)) {                  // NaN/Inf in this frame: the column comes out NaN
-        scale = (T)0;
-        inv_scale = tot - tot;
-      }
-      if (t == 0 && cur.valid) col_scale[fl] = inv_scale;
+    for (int f = 0; f < NFW; ++f) {
+      const int fl = cur[f].fl;
+      if constexpr (TXONLY) {
+        // ---- unpack, phase transform, bin index: branch-free; skipped bins contribute 0 ----
+        cpx<T> cv[9];
+        int dst[9];
+        T l1 = (T)0;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        if (q == 8 && t != 0) break;
-        atomicAdd(reinterpret_cast<UT*>(&tile_re[dst[q]]), (UT)to_fixed<T>(cv[q].x * scale));
-        if (p.squeezing != 1) atomicAdd(reinterpret_cast<UT*>(&tile_im[dst[q]]), (UT)to_fixed<T>(cv[q].y * scale));
-      }
-    } else {
+        for (int q = 0; q < 9; ++q) {
+          const int k = t + L * q;
+          const cpx<T> zk = v[f][q], zn = zp[f][q];
+          const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+          const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
+          T w = (T)0;
+          int kk = k;
+          bool keep = true;
+          if (!SSQ_ABL(8)) keep = phase_bin<T>(p, k, S, dS, w, kk);
+          keep = keep && cur[f].valid && (q < 8 || t == 0);
+          cpx<T> c = (p.squeezing == 1) ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
+          c.x = keep ? c.x : (T)0;
+          c.y = keep ? c.y : (T)0;
+          cv[q] = c;
+          dst[q] = (keep ? kk : 0) * PITCH + fl;
+          l1 += fabs(c.x) + fabs(c.y);
+        }
+        // fixed-point scatter: every partial sum of this column is bounded by its L1 mass dw*sum|c|;
+        // pick 2^e above it and accumulate round(c * dw * 2^(FRAC-e)) with integer LDS atomics
+        const T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t) * p.dw;
+        int e = 0;
+        (void)frexp(tot, &e);
+        if (e < C::EMIN) e = C::EMIN;
+        T scale = ldexp(p.dw, C::FRAC - e);          // weight * dw  (ssq_stft.rs:298), then fixed point
+        T inv_scale = ldexp((T)1, e - C::FRAC);
+        if (!(tot < (T)INFINITY)) {                  // NaN/Inf in this frame: the column comes out NaN
+          scale = (T)0;
+          inv_scale = tot - tot;
+        }
+        if (t == 0 && cur[f].valid) col_scale[fl] = inv_scale;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        if (q == 8 && t != 0) break;
-        if (!cur.valid) continue;
-        const int k = t + L * q;
-        const cpx<T> zk = v[q], zn = zp[q];
-        const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
-        const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};
-        const int o = k * PITCH + fl;
-        if (p.out_kind == 1) {                     // SSQ_OUT_SX
-          tile_re[o] = as_int<T>(S.x);
-          tile_im[o] = as_int<T>(S.y);
-        } else if (p.out_kind == 2) {              // SSQ_OUT_DSX
-          tile_re[o] = as_int<T>(dS.x * p.inv_alpha);
-          tile_im[o] = as_int<T>(dS.y * p.inv_alpha);
-        } else {                                   // SSQ_OUT_WK
-          T w;
-          int kk;
-          const bool keep = phase_bin<T>(p, k, S, dS, w, kk);
-          tile_re[o] = as_int<T>(w);
-          tile_im[o] = as_int<T>(keep ? (T)kk : (T)-1);
+        for (int q = 0; q < 9; ++q) {
+          if (q == 8 && t != 0) break;
+          atomicAdd(reinterpret_cast<UT*>(&tile_re[dst[q]]), (UT)to_fixed<T>(cv[q].x * scale));
+          if (p.squeezing != 1)
+            atomicAdd(reinterpret_cast<UT*>(&tile_im[dst[q]]), (UT)to_fixed<T>(cv[q].y * scale));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          if (q == 8 && t != 0) break;
+          if (!cur[f].valid) continue;
+          const int k = t + L * q;
+          const cpx<T> zk = v[f][q], zn = zp[f][q];
+          const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+          const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};
+          const int o = k * PITCH + fl;
+          if (p.out_kind == 1) {                     // SSQ_OUT_SX
+            tile_re[o] = as_int<T>(S.x);
+            tile_im[o] = as_int<T>(S.y);
+          } else if (p.out_kind == 2) {              // SSQ_OUT_DSX
+            tile_re[o] = as_int<T>(dS.x * p.inv_alpha);
+            tile_im[o] = as_int<T>(dS.y * p.inv_alpha);
+          } else {                                   // SSQ_OUT_WK
+            T w;
+            int kk;
+            const bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+            tile_re[o] = as_int<T>(w);
+            tile_im[o] = as_int<T>(keep ? (T)kk : (T)-1);
+          }
         }
       }
     }
 
-    if (it == C::ITERS - 1) {
+    if (ig == NG - 1 && !SSQ_ABL(64)) {
       __syncthreads();
       // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
-      cpx<T>* __restrict__ og = p.out + cur.sig * (long long)NF * p.n_frames + cur.frame0;
+      cpx<T>* __restrict__ og = p.out + tl.sig * (long long)NF * p.n_frames + tl.frame0;
       for (int i = tid; i < NF * F; i += C::W * 64) {
         const int k = i / F, f = i % F;
         const int o = k * PITCH + f;
@@ -365,14 +428,15 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         } else {
           val = {from_int<T>(ire), from_int<T>(iim)};
         }
-        if (cur.frame0 + f < p.n_frames) og[(long long)k * p.n_frames + f] = val;
+        if (tl.frame0 + f < p.n_frames && !SSQ_ABL(32)) og[(long long)k * p.n_frames + f] = val;
       }
       __syncthreads();
     }
     if (!has_next) break;
-    tile = ntile;
-    it = nit;
-    cur = nxt;
+    tl = ntl;
+    ig = nig;
+#pragma unroll
+    for (int f = 0; f < NFW; ++f) cur[f] = nxt[f];
   }
 }
 

@@ -167,7 +167,7 @@ def _check_ssq_f32(x32, win, n_fft, hop, fs, pad="reflect", squeezing="sum"):
     # round the other way there, so allow isolated neighbour swaps but not a changed column sum)
     tmax = np.abs(Tx_re).max()
     assert (np.abs(Tx - Tx_re) > 2e-5 * tmax).mean() <= 5e-4
-    assert np.abs(Tx.sum(0) - Tx_re.sum(0)).max() <= 2e-5 * tmax
+    assert np.abs(Tx.astype(np.complex128).sum(0) - Tx_re.sum(0)).max() <= 2e-5 * tmax
     # (d) end-to-end against the fp64 oracle: per-column energy moves at most between neighbours
     keep_o = ~np.isinf(im["w"])
     both = keep_o & keep_g & (np.abs(im["Sx"]) > 1e-3 * smax)
