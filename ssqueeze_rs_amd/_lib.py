@@ -11,7 +11,7 @@ import re
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssq_hip.so")
+LIB_PATH = os.environ.get("SSQ_HIP_LIB") or os.path.join(_HERE, "libssq_hip.so")   # env: diagnostic builds only
 HEADER_PATH = os.path.join(_HERE, "..", "include", "ssq_hip.h")
 
 SSQ_F32, SSQ_F64 = 0, 1

@@ -19,7 +19,7 @@ ARCH = "gfx950"
 
 SOURCES = ["api_common.hip", "api_stft.hip", "stft_fused.hip", "stft_generic.hip",
            "api_cwt.hip", "cwt_kernels.hip"]
-CXXFLAGS = ["-std=c++17", "-O3", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+CXXFLAGS = ["-std=c++17", "-O3", "-fno-slp-vectorize", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-value"]
 
 
@@ -37,19 +37,23 @@ def _newer(src_list, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build_lib(force: bool = False, verbose: bool = True) -> str:
+def build_lib(force: bool = False, verbose: bool = True, extra_flags=(), suffix: str = "") -> str:
+    """suffix/extra_flags build a diagnostic variant (e.g. -DSSQ_STAMPS) next to the product library."""
+    global OBJ_DIR, LIB
+    lib = LIB if not suffix else LIB.replace(".so", f"_{suffix}.so")
+    obj_dir = OBJ_DIR if not suffix else OBJ_DIR + "_" + suffix
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "ssq_hip.h"))
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     objs = []
     for s in srcs:
-        o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
+        o = os.path.join(obj_dir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _newer([s] + headers, o):
-            jobs.append([hipcc, *CXXFLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *CXXFLAGS, *extra_flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -62,10 +66,13 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(objs, LIB):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _newer(objs, lib):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    if "--stamps" in sys.argv:
+        print(build_lib(extra_flags=("-DSSQ_STAMPS", "-DSSQ_ABLATE_HOOKS"), suffix="diag"))
+    else:
+        print(build_lib(force="--force" in sys.argv))

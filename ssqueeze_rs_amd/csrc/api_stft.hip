@@ -99,6 +99,8 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   {
     const char* ab = std::getenv("SSQ_ABLATE");
     p.ablate = ab ? std::atoi(ab) : 0;
+    const char* st = std::getenv("SSQ_STAMPS_PTR");   // diagnostic builds: device buffer address
+    p.stamps = st ? (unsigned long long*)std::strtoull(st, nullptr, 0) : nullptr;
   }
   return p;
 }

@@ -127,6 +127,53 @@ __device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
   return v;
 }
 
+// Hot-path variant of phase_bin (stft_kernels.h) for the TX kernel: same arithmetic, fewer
+// instructions.  Returns keep; `dS` is alpha*dSx (alpha is inside p.two_pi_eff).
+template <typename T>
+__device__ __forceinline__ bool phase_bin_fast(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, int& kk_out) {
+  if constexpr (sizeof(T) == 4) {
+    const float den = S.x * S.x + S.y * S.y;
+    const float num = dS.y * S.x - dS.x * S.y;
+    const float pd = num * __builtin_amdgcn_rcpf(den * p.two_pi_eff);
+    const float w = fabsf((float)i * p.sfs_step - pd);
+    // |Sx| < gamma, or w infinite (:23, :278).  A NaN w can only come from non-finite samples, and
+    // those make the whole column NaN through column_scale, so it may be dropped here.
+    const bool keep = (den >= p.gamma2) && (w <= 3.402823466e+38f);
+    const float u = __builtin_fmaf(w, p.inv_dw, -0.5f);
+    kk_out = (int)fminf(__builtin_ceilf(u), (float)(p.n_freqs - 1));
+    return keep;
+  } else {
+    T w;
+    return phase_bin<T>(p, i, S, dS, w, kk_out);
+  }
+}
+
+// Power-of-two fixed-point scale of a column: 2^e > tot, scale = dw * 2^(FRAC-e), inv = 2^(e-FRAC).
+template <typename T, int FRAC, int EMIN>
+__device__ __forceinline__ void column_scale(T tot, T dw, T& scale, T& inv_scale) {
+  if constexpr (sizeof(T) == 4) {
+    const int ex = (__float_as_int(tot) >> 23) & 0xff;          // tot >= 0
+    int e = ex - 126;                                            // frexp exponent: tot < 2^e
+    e = e < EMIN ? EMIN : e;
+    scale = dw * __int_as_float((127 + FRAC - e) << 23);
+    inv_scale = __int_as_float((127 + e - FRAC) << 23);
+    if (ex == 255) {                                             // NaN/Inf: the column comes out NaN
+      scale = 0.0f;
+      inv_scale = __int_as_float(0x7fc00000);
+    }
+  } else {
+    int e = 0;
+    (void)frexp(tot, &e);
+    if (e < EMIN) e = EMIN;
+    scale = ldexp(dw, FRAC - e);
+    inv_scale = ldexp((T)1, e - FRAC);
+    if (!(tot < (T)INFINITY)) {
+      scale = (T)0;
+      inv_scale = tot - tot;
+    }
+  }
+}
+
 // one unit of work of a lane: frame `fl` of tile (sig, ft) -> where its samples are
 template <typename T>
 struct FrameItem {
@@ -182,6 +229,33 @@ __device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem
       xv[q] = w.valid ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
   }
 }
+
+#ifdef SSQ_STAMPS
+// In-kernel phase stamps (diagnostic build only; never quote its run time, read its SHARES).
+__device__ __forceinline__ unsigned long long ssq_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define SSQ_STAMP(i)                         \
+  do {                                       \
+    const unsigned long long t_ = ssq_stamp(); \
+    st_acc[i] += t_ - st_prev;               \
+    st_prev = t_;                            \
+  } while (0)
+#elif defined(SSQ_MARK)
+// static section markers for instruction counting in the .s (tools/count_sections.py)
+#define SSQ_STAMP(i)                                   \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    asm volatile("; SSQ_SECTION " #i ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#else
+#define SSQ_STAMP(i) do { } while (0)
+#endif
 
 #ifdef SSQ_ABLATE_HOOKS
 #define SSQ_ABL(mask) (p.ablate & (mask))       // timing experiments (tools/ablate.sh); results are wrong
@@ -257,58 +331,84 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   __syncthreads();
 
   if ((long long)blockIdx.x >= p.total_tiles) return;
-  // (sig, ft) advance by gridDim.x tiles per step without a 64-bit division per frame
-  TileItem tl = make_tile<T, LOGN>(p, (long long)(blockIdx.x / (unsigned)p.tiles_per_signal),
-                                   (int)(blockIdx.x % (unsigned)p.tiles_per_signal));
-  int ig = 0;
-  FrameItem<T> cur[NFW];
-  T xn[NFW][16];
-#pragma unroll
-  for (int f = 0; f < NFW; ++f) {
-    cur[f] = make_frame<T, LOGN>(p, tl, ig * NFW + f, slot, t);
-    load_samples<T, LOGN>(p, tl, cur[f], xn[f]);
-  }
+  // Work items of this lane: (tile, frame group).  Samples are prefetched TWO items ahead, so that
+  // the loads of the next tile never queue behind this tile's read-out burst of stores.
+  struct Item {
+    TileItem tl;
+    int ig;
+    bool ok;
+  };
   const long long n_sig = p.total_tiles / p.tiles_per_signal;
-
-#pragma unroll 1
-  while (true) {
-    // ---- window multiply; then prefetch the next frames' samples behind this group's FFTs ----
-    cpx<T> v[NFW][16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : p.win2[t + L * q];
-#pragma unroll
-      for (int f = 0; f < NFW; ++f) v[f][q] = {xn[f][q] * wq.x, xn[f][q] * wq.y};
-    }
-    TileItem ntl = tl;
-    int nig = ig + 1;
-    if (nig == NG) {
-      nig = 0;
-      long long ns = tl.sig;
-      int nft = tl.ft + (int)gridDim.x;
+  auto advance = [&](const Item& c) {
+    Item n = c;
+    n.ig = c.ig + 1;
+    if (n.ig == NG) {
+      n.ig = 0;
+      long long ns = c.tl.sig;
+      int nft = c.tl.ft + (int)gridDim.x;
       while (nft >= p.tiles_per_signal) {
         nft -= p.tiles_per_signal;
         ++ns;
       }
-      ntl = make_tile<T, LOGN>(p, ns, nft);
+      n.tl = make_tile<T, LOGN>(p, ns, nft);
     }
-    const bool has_next = ntl.sig < n_sig;
-    FrameItem<T> nxt[NFW];
+    n.ok = c.ok && (n.tl.sig < n_sig);
+    return n;
+  };
+  Item i0;
+  i0.tl = make_tile<T, LOGN>(p, (long long)(blockIdx.x / (unsigned)p.tiles_per_signal),
+                             (int)(blockIdx.x % (unsigned)p.tiles_per_signal));
+  i0.ig = 0;
+  i0.ok = true;
+  Item i1 = advance(i0);
+  static_assert(NFW == 1, "frame pairing is parked (see PAIR)");
+  FrameItem<T> cur[NFW];
+  T xn[NFW][16];      // samples of the current item
+  T xb[16];           // samples of the next item
+  cur[0] = make_frame<T, LOGN>(p, i0.tl, i0.ig, slot, t);
+  load_samples<T, LOGN>(p, i0.tl, cur[0], xn[0]);
+  FrameItem<T> fr1 = cur[0];
+  if (i1.ok) {
+    fr1 = make_frame<T, LOGN>(p, i1.tl, i1.ig, slot, t);
+    load_samples<T, LOGN>(p, i1.tl, fr1, xb);
+  }
+#ifdef SSQ_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = ssq_stamp();
+#endif
+
+#pragma unroll 1
+  while (true) {
+    const TileItem tl = i0.tl;
+    const int ig = i0.ig;
+    // ---- window multiply ----
+    cpx<T> v[NFW][16];
 #pragma unroll
-    for (int f = 0; f < NFW; ++f) {
-      nxt[f] = cur[f];
-      if (has_next) {
-        nxt[f] = make_frame<T, LOGN>(p, ntl, nig * NFW + f, slot, t);
-        if (!SSQ_ABL(1)) load_samples<T, LOGN>(p, ntl, nxt[f], xn[f]);
-      }
+    for (int q = 0; q < 16; ++q) {
+      const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : p.win2[t + L * q];
+      v[0][q] = {xn[0][q] * wq.x, xn[0][q] * wq.y};
+    }
+    SSQ_STAMP(0);
+    const bool has_next = i1.ok;
+    // rotate the prefetch ring: the next item's samples (loaded one iteration ago) move to xn and the
+    // loads of the item after next go out now, a full iteration before they are needed
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xn[0][q] = xb[q];
+    const Item i2 = advance(i1);
+    FrameItem<T> fr2 = fr1;
+    if (i2.ok) {
+      fr2 = make_frame<T, LOGN>(p, i2.tl, i2.ig, slot, t);
+      if (!SSQ_ABL(1)) load_samples<T, LOGN>(p, i2.tl, fr2, xb);
     }
 
+    SSQ_STAMP(1);
     if (!SSQ_ABL(2)) {
       if constexpr (PAIR) fft_pass_pair<T, LOGN, 0, false, false>(v[0], v[1], exch, twr, tw_src, t);
       else fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
     }
     // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
 
+    SSQ_STAMP(2);
     // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
     cpx<T> zp[NFW][9];
 #pragma unroll
@@ -338,51 +438,57 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       }
     }
 
+    SSQ_STAMP(3);
 #pragma unroll
     for (int f = 0; f < NFW; ++f) {
       const int fl = cur[f].fl;
       if constexpr (TXONLY) {
         // ---- unpack, phase transform, bin index: branch-free; skipped bins contribute 0 ----
         cpx<T> cv[9];
-        int dst[9];
+        int dstb[9];                                 // byte offset of the destination inside a plane
         T l1 = (T)0;
+        const int fl4 = fl * (int)sizeof(T);
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           const int k = t + L * q;
           const cpx<T> zk = v[f][q], zn = zp[f][q];
           const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
           const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
-          T w = (T)0;
           int kk = k;
           bool keep = true;
-          if (!SSQ_ABL(8)) keep = phase_bin<T>(p, k, S, dS, w, kk);
+          if (!SSQ_ABL(8)) keep = phase_bin_fast<T>(p, k, S, dS, kk);
           keep = keep && cur[f].valid && (q < 8 || t == 0);
           cpx<T> c = (p.squeezing == 1) ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
           c.x = keep ? c.x : (T)0;
           c.y = keep ? c.y : (T)0;
           cv[q] = c;
-          dst[q] = (keep ? kk : 0) * PITCH + fl;
+          dstb[q] = __mul24(keep ? kk : 0, PITCH * (int)sizeof(T)) + fl4;   // 24-bit multiply: full rate
           l1 += fabs(c.x) + fabs(c.y);
         }
+        SSQ_STAMP(4);
         // fixed-point scatter: every partial sum of this column is bounded by its L1 mass dw*sum|c|;
         // pick 2^e above it and accumulate round(c * dw * 2^(FRAC-e)) with integer LDS atomics
         const T tot = frame_allreduce<T, L, MULTIWAVE>(l1, lane, reinterpret_cast<T*>(exch), t) * p.dw;
-        int e = 0;
-        (void)frexp(tot, &e);
-        if (e < C::EMIN) e = C::EMIN;
-        T scale = ldexp(p.dw, C::FRAC - e);          // weight * dw  (ssq_stft.rs:298), then fixed point
-        T inv_scale = ldexp((T)1, e - C::FRAC);
-        if (!(tot < (T)INFINITY)) {                  // NaN/Inf in this frame: the column comes out NaN
-          scale = (T)0;
-          inv_scale = tot - tot;
-        }
+        T scale, inv_scale;
+        column_scale<T, C::FRAC, C::EMIN>(tot, p.dw, scale, inv_scale);
         if (t == 0 && cur[f].valid) col_scale[fl] = inv_scale;
+        SSQ_STAMP(5);
+        char* pre = reinterpret_cast<char*>(tile_re);
+        char* pim = reinterpret_cast<char*>(tile_im);
+        if (p.squeezing == 1) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          if (q == 8 && t != 0) break;
-          atomicAdd(reinterpret_cast<UT*>(&tile_re[dst[q]]), (UT)to_fixed<T>(cv[q].x * scale));
-          if (p.squeezing != 1)
-            atomicAdd(reinterpret_cast<UT*>(&tile_im[dst[q]]), (UT)to_fixed<T>(cv[q].y * scale));
+          for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
+          if (t == 0) atomicAdd(reinterpret_cast<UT*>(pre + dstb[8]), (UT)to_fixed<T>(cv[8].x * scale));
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
+            atomicAdd(reinterpret_cast<UT*>(pim + dstb[q]), (UT)to_fixed<T>(cv[q].y * scale));
+          }
+          if (t == 0) {
+            atomicAdd(reinterpret_cast<UT*>(pre + dstb[8]), (UT)to_fixed<T>(cv[8].x * scale));
+            atomicAdd(reinterpret_cast<UT*>(pim + dstb[8]), (UT)to_fixed<T>(cv[8].y * scale));
+          }
         }
       } else {
 #pragma unroll
@@ -411,32 +517,61 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       }
     }
 
+    SSQ_STAMP(6);
     if (ig == NG - 1 && !SSQ_ABL(64)) {
       __syncthreads();
+      SSQ_STAMP(7);
       // ---- tile read-out: row segments of F frames, re-zeroing as we go ----
-      cpx<T>* __restrict__ og = p.out + tl.sig * (long long)NF * p.n_frames + tl.frame0;
-      for (int i = tid; i < NF * F; i += C::W * 64) {
-        const int k = i / F, f = i % F;
-        const int o = k * PITCH + f;
-        const IT ire = tile_re[o], iim = tile_im[o];
-        tile_re[o] = 0;
-        tile_im[o] = 0;
-        cpx<T> val;
-        if constexpr (TXONLY) {
-          const T sc = col_scale[f];
-          val = {(T)ire * sc, (T)iim * sc};
+      // thread -> (fixed frame f, rows k0, k0 + RSTEP, ...): LDS offsets and the global row stride are
+      // loop constants, so an element costs 2 reads + 2 zero-writes + convert + one 8-byte store
+      {
+        constexpr int NT = C::W * 64;
+        constexpr int RSTEP = NT / F;                  // rows covered per sweep
+        static_assert(NT % F == 0, "threads per block must be a multiple of F");
+        const int f = tid % F;
+        const int k0 = tid / F;
+        cpx<T>* __restrict__ og =
+            p.out + tl.sig * (long long)NF * p.n_frames + tl.frame0 + f + (long long)k0 * p.n_frames;
+        const long long gstep = (long long)RSTEP * p.n_frames;
+        const bool fvalid = (tl.frame0 + f < p.n_frames) && !SSQ_ABL(32);
+        const T sc = TXONLY ? col_scale[f] : (T)1;
+        IT* tr = tile_re + k0 * PITCH + f;
+        IT* ti = tile_im + k0 * PITCH + f;
+        constexpr int NFULL = NF / RSTEP;              // sweeps in which every thread has a row
+        auto sweep = [&](int j, bool store) {
+          const IT ire = tr[j * RSTEP * PITCH], iim = ti[j * RSTEP * PITCH];
+          tr[j * RSTEP * PITCH] = 0;
+          ti[j * RSTEP * PITCH] = 0;
+          cpx<T> val;
+          if constexpr (TXONLY) val = {(T)ire * sc, (T)iim * sc};
+          else val = {from_int<T>(ire), from_int<T>(iim)};
+          if (store) og[j * gstep] = val;
+        };
+        if (fvalid) {
+#pragma unroll 8
+          for (int j = 0; j < NFULL; ++j) sweep(j, true);
+          if (k0 + NFULL * RSTEP < NF) sweep(NFULL, true);
         } else {
-          val = {from_int<T>(ire), from_int<T>(iim)};
+#pragma unroll 8
+          for (int j = 0; j < NFULL; ++j) sweep(j, false);
+          if (k0 + NFULL * RSTEP < NF) sweep(NFULL, false);
         }
-        if (tl.frame0 + f < p.n_frames && !SSQ_ABL(32)) og[(long long)k * p.n_frames + f] = val;
       }
+      SSQ_STAMP(8);
       __syncthreads();
+      SSQ_STAMP(9);
     }
+#ifdef SSQ_STAMPS
+    if (!has_next) {
+      if (p.stamps && lane == 0)
+        for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * C::W + wave) * 12 + i] = st_acc[i];
+    }
+#endif
     if (!has_next) break;
-    tl = ntl;
-    ig = nig;
-#pragma unroll
-    for (int f = 0; f < NFW; ++f) cur[f] = nxt[f];
+    i0 = i1;
+    i1 = i2;
+    cur[0] = fr1;
+    fr1 = fr2;
   }
 }
 

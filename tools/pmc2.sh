@@ -1,0 +1,33 @@
+#!/bin/bash
+# second set of PMC passes: instruction fetch, VMEM/LDS FIFO stalls, TA/TCP (L1) behaviour
+set -o pipefail
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc2_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+PASSES=(
+ "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL"
+ "SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+ "TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_TOTAL_WAVEFRONTS"
+ "TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ"
+ "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_TOTAL_CACHE_ACCESSES TCP_CACHE_MISS"
+ "TCP_TCC_WRITE_REQ_LATENCY TCP_TCP_TA_DATA_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_TA_TCP_STATE_READ"
+)
+i=0
+for P in "${PASSES[@]}"; do
+  i=$((i+1))
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(list)
+for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "stft_fused" in r["Kernel_Name"] or "cwt_" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
+with open("$OUT/summary.txt", "w") as o:
+    for (k, c), v in sorted(agg.items()):
+        line = f"{c:34s} n={len(v):3d} mean={sum(v)/len(v):.6g}"
+        print(line); o.write(line + "\n")
+PY

@@ -1,0 +1,42 @@
+"""Per-phase cycle shares of the fused kernel from a -DSSQ_STAMPS diagnostic build.
+    python -m ssqueeze_rs_amd.build --stamps && SSQ_HIP_LIB=ssqueeze_rs_amd/libssq_hip_diag.so python tools/stamps.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ssqueeze_rs_amd import _lib  # noqa: E402
+
+NAMES = ["wait prefetch + window", "decode + issue loads", "FFT (3 passes, 2 LDS exchanges)", "partner shuffles",
+         "unpack + phase + bins", "column reduce + scale", "atomics (+drain)", "barrier 1 wait", "read-out",
+         "barrier 2 wait", "-", "-"]
+lib = _lib.load()
+B, N, n_fft, hop = 64, 1 << 20, 1024, 256
+buf = C.c_void_p()
+nwaves = 256 * 8
+_lib.check(lib.ssq_dev_malloc(C.byref(buf), nwaves * 12 * 8))
+_lib.check(lib.ssq_dev_memset(buf, 0, nwaves * 12 * 8, None))
+os.environ["SSQ_STAMPS_PTR"] = str(buf.value)
+win = np.hanning(n_fft)
+plan = C.c_void_p()
+_lib.check(lib.ssq_stft_plan_create(C.byref(plan), 0, N, win.ctypes.data_as(C.c_void_p), n_fft, hop, 1.0, 0, 0, -1.0, 0))
+dx, do = C.c_void_p(), C.c_void_p()
+_lib.check(lib.ssq_dev_malloc(C.byref(dx), B * N * 4))
+_lib.check(lib.ssq_dev_malloc(C.byref(do), B * 513 * 4096 * 8))
+x = np.random.default_rng(0).standard_normal(B * N).astype(np.float32)
+_lib.check(lib.ssq_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes, None))
+for _ in range(2):
+    _lib.check(lib.ssq_stft_plan_exec(plan, 0, dx, B, do, None, 0, None))
+_lib.check(lib.ssq_device_sync())
+out = np.zeros(nwaves * 12, dtype=np.uint64)
+_lib.check(lib.ssq_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, None))
+_lib.check(lib.ssq_device_sync())
+acc = out.reshape(nwaves, 12).astype(np.float64)
+tot = acc.sum(1).mean()
+frames_per_wave = B * 4096 / nwaves
+print(f"mean cycles per wave {tot:.0f}; per frame {tot / frames_per_wave:.0f}")
+for i, n in enumerate(NAMES[:10]):
+    print(f"{n:36s} {acc[:, i].mean() / frames_per_wave:9.0f} cyc/frame  {100 * acc[:, i].mean() / tot:5.1f} %")
