@@ -84,6 +84,9 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.padtype = pl->padtype;
   const int F = pl->tile_frames > 0 ? pl->tile_frames : 1;
   p.tiles_per_signal = (pl->n_frames + F - 1) / F;
+  p.ta0 = 0;
+  p.ta_n = p.tiles_per_signal;
+  p.tb0 = 0;
   p.total_tiles = (long long)p.tiles_per_signal * batch;
   p.out_kind = out_kind;
   p.squeezing = pl->squeezing;
@@ -110,7 +113,7 @@ int exec_typed(ssq_stft_plan* pl, int out_kind, const void* d_x, long long batch
                void* d_ws, long long ws_bytes, hipStream_t stream) {
   StftDev<T> p = make_dev<T>(pl, out_kind, d_x, d_out, batch);
   if (pl->fused) {
-    SSQ_HIP(launch_stft_fused<T>(p, pl->n_fft, pl->cu_count, stream));
+    SSQ_HIP(launch_stft_fused<T>(p, pl->n_fft, pl->cu_count, batch, stream));
     return 0;
   }
   const long long bins = batch * (long long)pl->n_freqs * pl->n_frames;

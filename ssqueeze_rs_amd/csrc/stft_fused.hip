@@ -180,7 +180,8 @@ struct FrameItem {
   const T* xs;          // signal base
   long long pos0;       // original-signal index of this lane's element q = 0
   int fl;               // frame index inside the tile
-  bool valid;           // frame < n_frames
+  int valid;            // frame < n_frames  (int, not bool: sub-dword struct members end up in an
+                        // LDS-promoted alloca with unaligned 16-bit accesses = 64-cycle replays)
 };
 
 // a tile of F frames of one signal
@@ -188,39 +189,37 @@ struct TileItem {
   long long sig;
   int ft;               // tile index inside the signal
   int frame0;           // first frame
-  bool interior;        // no frame of the tile needs padding
 };
 
+// j = index of the tile among those this launch covers for one signal (StftDev::ta0/ta_n/tb0)
 template <typename T, int LOGN>
-__device__ __forceinline__ TileItem make_tile(const StftDev<T>& p, long long sig, int ft) {
+__device__ __forceinline__ TileItem make_tile(const StftDev<T>& p, long long sig, int j) {
   using C = FusedCfg<T, LOGN>;
   TileItem w;
   w.sig = sig;
-  w.ft = ft;
+  w.ft = j;
+  const int ft = (j < p.ta_n) ? p.ta0 + j : p.tb0 + (j - p.ta_n);
   w.frame0 = ft * C::F;
-  const long long first = (long long)w.frame0 * p.hop - p.pad_left;
-  w.interior = (first >= 0) && (first + (long long)(C::F - 1) * p.hop + C::N <= p.n_signal) &&
-               (w.frame0 + C::F <= p.n_frames);
   return w;
 }
 
-template <typename T, int LOGN>
+template <typename T, int LOGN, bool EDGE>
 __device__ __forceinline__ FrameItem<T> make_frame(const StftDev<T>& p, const TileItem& tl, int it, int slot, int t) {
   using C = FusedCfg<T, LOGN>;
   FrameItem<T> w;
   w.fl = it * C::FIF + slot;
   const int frame = tl.frame0 + w.fl;
-  w.valid = frame < p.n_frames;
+  w.valid = EDGE ? ((frame < p.n_frames) ? 1 : 0) : 1;
   w.xs = p.x + tl.sig * p.n_signal;
   w.pos0 = (long long)frame * p.hop - p.pad_left + t;
   return w;
 }
 
-template <typename T, int LOGN>
+template <typename T, int LOGN, bool EDGE>
 __device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem& tl, const FrameItem<T>& w,
                                              T (&xv)[16]) {
   constexpr int L = FusedCfg<T, LOGN>::L;
-  if (tl.interior) {
+  if constexpr (!EDGE) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
   } else {
@@ -267,7 +266,9 @@ __device__ __forceinline__ unsigned long long ssq_stamp() {
 //                 a wave runs its two frames of a tile staggered, so one frame's LDS round trips
 //                 hide behind the other frame's arithmetic)
 // TXONLY = false: SSQ_OUT_SX / DSX / WK  (stft and the test hooks)
-template <typename T, int LOGN, bool TXONLY>
+// EDGE = false: tiles whose frames all lie inside the signal (direct loads, every frame valid);
+// EDGE = true : the few tiles per signal that touch a boundary (padding by index mirroring).
+template <typename T, int LOGN, bool TXONLY, bool EDGE>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   struct Item {
     TileItem tl;
     int ig;
-    bool ok;
+    int ok;
   };
   const long long n_sig = p.total_tiles / p.tiles_per_signal;
   auto advance = [&](const Item& c) {
@@ -352,25 +353,25 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       }
       n.tl = make_tile<T, LOGN>(p, ns, nft);
     }
-    n.ok = c.ok && (n.tl.sig < n_sig);
+    n.ok = (c.ok && (n.tl.sig < n_sig)) ? 1 : 0;
     return n;
   };
   Item i0;
   i0.tl = make_tile<T, LOGN>(p, (long long)(blockIdx.x / (unsigned)p.tiles_per_signal),
                              (int)(blockIdx.x % (unsigned)p.tiles_per_signal));
   i0.ig = 0;
-  i0.ok = true;
+  i0.ok = 1;
   Item i1 = advance(i0);
   static_assert(NFW == 1, "frame pairing is parked (see PAIR)");
   FrameItem<T> cur[NFW];
   T xn[NFW][16];      // samples of the current item
   T xb[16];           // samples of the next item
-  cur[0] = make_frame<T, LOGN>(p, i0.tl, i0.ig, slot, t);
-  load_samples<T, LOGN>(p, i0.tl, cur[0], xn[0]);
+  cur[0] = make_frame<T, LOGN, EDGE>(p, i0.tl, i0.ig, slot, t);
+  load_samples<T, LOGN, EDGE>(p, i0.tl, cur[0], xn[0]);
   FrameItem<T> fr1 = cur[0];
   if (i1.ok) {
-    fr1 = make_frame<T, LOGN>(p, i1.tl, i1.ig, slot, t);
-    load_samples<T, LOGN>(p, i1.tl, fr1, xb);
+    fr1 = make_frame<T, LOGN, EDGE>(p, i1.tl, i1.ig, slot, t);
+    load_samples<T, LOGN, EDGE>(p, i1.tl, fr1, xb);
   }
 #ifdef SSQ_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -397,8 +398,8 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
     const Item i2 = advance(i1);
     FrameItem<T> fr2 = fr1;
     if (i2.ok) {
-      fr2 = make_frame<T, LOGN>(p, i2.tl, i2.ig, slot, t);
-      if (!SSQ_ABL(1)) load_samples<T, LOGN>(p, i2.tl, fr2, xb);
+      fr2 = make_frame<T, LOGN, EDGE>(p, i2.tl, i2.ig, slot, t);
+      if (!SSQ_ABL(1)) load_samples<T, LOGN, EDGE>(p, i2.tl, fr2, xb);
     }
 
     SSQ_STAMP(1);
@@ -582,19 +583,50 @@ bool fused_supported(int n_fft) {
 }
 
 template <typename T, int LOGN>
-static hipError_t launch_one(const StftDev<T>& p, int cu_count, hipStream_t stream) {
+static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch, hipStream_t stream) {
   using C = FusedCfg<T, LOGN>;
-  int per_cu = C::LDS_MAX / C::LDS_BYTES;
+  int per_cu = (160 * 1024) / C::LDS_BYTES;
   if (per_cu < 1) per_cu = 1;
   if (per_cu * C::W > 32) per_cu = 32 / C::W;
-  long long blocks = (long long)cu_count * per_cu;
-  if (blocks > p.total_tiles) blocks = p.total_tiles;
-  if (blocks < 1) return hipSuccess;
-  if (p.out_kind == 0)
-    hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
-  else
-    hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false>), dim3((unsigned)blocks), dim3(C::W * 64), 0, stream, p);
-  return hipGetLastError();
+  // interior tiles [lo, hi): every frame of the tile reads only inside the signal
+  const long long span = (long long)C::F * p0.hop;
+  const int tps_all = (p0.n_frames + C::F - 1) / C::F;
+  long long lo = (p0.pad_left + span - 1) / span;
+  long long hi_num = p0.n_signal - C::N - (long long)(C::F - 1) * p0.hop + p0.pad_left;
+  long long hi = hi_num >= 0 ? hi_num / span + 1 : 0;
+  const long long full = p0.n_frames / C::F;
+  if (hi > full) hi = full;
+  if (lo > tps_all) lo = tps_all;
+  if (hi < lo) hi = lo;
+  for (int edge = 0; edge < 2; ++edge) {
+    StftDev<T> p = p0;
+    if (!edge) {
+      p.ta0 = (int)lo;
+      p.ta_n = (int)(hi - lo);
+      p.tb0 = 0;
+      p.tiles_per_signal = p.ta_n;
+    } else {
+      p.ta0 = 0;
+      p.ta_n = (int)lo;
+      p.tb0 = (int)hi;
+      p.tiles_per_signal = (int)lo + (tps_all - (int)hi);
+    }
+    p.total_tiles = (long long)p.tiles_per_signal * batch;
+    if (p.total_tiles <= 0) continue;
+    long long blocks = (long long)cu_count * per_cu;
+    if (blocks > p.total_tiles) blocks = p.total_tiles;
+    const dim3 g((unsigned)blocks), b(C::W * 64);
+    if (p.out_kind == 0) {
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false>), g, b, 0, stream, p);
+    } else {
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, true>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, false>), g, b, 0, stream, p);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <typename T>
@@ -612,15 +644,15 @@ int fused_tile_frames(int n_fft) {
 }
 
 template <typename T>
-hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, hipStream_t stream) {
+hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, long long batch, hipStream_t stream) {
   switch (n_fft) {
-    case 64: return launch_one<T, 6>(p, cu_count, stream);
-    case 128: return launch_one<T, 7>(p, cu_count, stream);
-    case 256: return launch_one<T, 8>(p, cu_count, stream);
-    case 512: return launch_one<T, 9>(p, cu_count, stream);
-    case 1024: return launch_one<T, 10>(p, cu_count, stream);
-    case 2048: return launch_one<T, 11>(p, cu_count, stream);
-    case 4096: return launch_one<T, 12>(p, cu_count, stream);
+    case 64: return launch_one<T, 6>(p, cu_count, batch, stream);
+    case 128: return launch_one<T, 7>(p, cu_count, batch, stream);
+    case 256: return launch_one<T, 8>(p, cu_count, batch, stream);
+    case 512: return launch_one<T, 9>(p, cu_count, batch, stream);
+    case 1024: return launch_one<T, 10>(p, cu_count, batch, stream);
+    case 2048: return launch_one<T, 11>(p, cu_count, batch, stream);
+    case 4096: return launch_one<T, 12>(p, cu_count, batch, stream);
   }
   return hipErrorInvalidValue;
 }
@@ -629,7 +661,7 @@ template bool fused_supported<float>(int);
 template bool fused_supported<double>(int);
 template int fused_tile_frames<float>(int);
 template int fused_tile_frames<double>(int);
-template hipError_t launch_stft_fused<float>(const StftDev<float>&, int, int, hipStream_t);
-template hipError_t launch_stft_fused<double>(const StftDev<double>&, int, int, hipStream_t);
+template hipError_t launch_stft_fused<float>(const StftDev<float>&, int, int, long long, hipStream_t);
+template hipError_t launch_stft_fused<double>(const StftDev<double>&, int, int, long long, hipStream_t);
 
 }  // namespace ssq

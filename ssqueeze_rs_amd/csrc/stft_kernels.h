@@ -19,7 +19,8 @@ struct StftDev {
   int hop;
   int pad_left;            // (n_fft-1)/2   stft_utils.rs:22
   int padtype;
-  int tiles_per_signal;
+  int tiles_per_signal;    // tiles of one signal covered by THIS launch: [ta0, ta0+ta_n) then [tb0, ...)
+  int ta0, ta_n, tb0;      // (interior tiles and edge tiles go to separate launches)
   int out_kind;            // SSQ_OUT_*
   int squeezing;
   T sfs_step;              // Sfs[i] = i*sfs_step          (ssq_stft.rs:255)
@@ -40,8 +41,9 @@ template <typename T>
 bool fused_supported(int n_fft);
 template <typename T>
 int fused_tile_frames(int n_fft);          // frames per output tile (F)
+// launches the interior-tile kernel (direct loads) and the edge-tile kernel (mirrored/zero padding)
 template <typename T>
-hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, hipStream_t stream);
+hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, long long batch, hipStream_t stream);
 
 // generic any-n_fft kernels (stft_generic.hip); tables are always double
 struct GenericTabs {
