@@ -268,7 +268,7 @@ __device__ __forceinline__ unsigned long long ssq_stamp() {
 // TXONLY = false: SSQ_OUT_SX / DSX / WK  (stft and the test hooks)
 // EDGE = false: tiles whose frames all lie inside the signal (direct loads, every frame valid);
 // EDGE = true : the few tiles per signal that touch a boundary (padding by index mirroring).
-template <typename T, int LOGN, bool TXONLY, bool EDGE>
+template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           bool keep = true;
           if (!SSQ_ABL(8)) keep = phase_bin_fast<T>(p, k, S, dS, kk);
           keep = keep && cur[f].valid && (q < 8 || t == 0);
-          cpx<T> c = (p.squeezing == 1) ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
+          cpx<T> c = LEB ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
           c.x = keep ? c.x : (T)0;
           c.y = keep ? c.y : (T)0;
           cv[q] = c;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         SSQ_STAMP(5);
         char* pre = reinterpret_cast<char*>(tile_re);
         char* pim = reinterpret_cast<char*>(tile_im);
-        if (p.squeezing == 1) {
+        if constexpr (LEB) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
           if (t == 0) atomicAdd(reinterpret_cast<UT*>(pre + dstb[8]), (UT)to_fixed<T>(cv[8].x * scale));
@@ -616,12 +616,15 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
     long long blocks = (long long)cu_count * per_cu;
     if (blocks > p.total_tiles) blocks = p.total_tiles;
     const dim3 g((unsigned)blocks), b(C::W * 64);
-    if (p.out_kind == 0) {
-      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true>), g, b, 0, stream, p);
-      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false>), g, b, 0, stream, p);
+    if (p.out_kind == 0 && p.squeezing == 1) {
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, true>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false, true>), g, b, 0, stream, p);
+    } else if (p.out_kind == 0) {
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, false>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false, false>), g, b, 0, stream, p);
     } else {
-      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, true>), g, b, 0, stream, p);
-      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, false>), g, b, 0, stream, p);
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, true, false>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, false, false>), g, b, 0, stream, p);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
