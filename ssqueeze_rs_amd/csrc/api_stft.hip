@@ -100,6 +100,22 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.two_pi_eff = (T)(6.283185307179586 * (pl->fused ? pl->alpha : 1.0));
   p.leb_unit = (T)(1.0 / (double)pl->n_freqs);
   {
+    // keep  <=>  den >= g2 (fp32 values).  With BIG = 1/ulp(g2): (den - g2)*BIG is 0 at equality and <= -1 for every
+    // representable den < g2, so clamp(den*BIG + (1 - g2*BIG)) is exactly the 0/1 mask (g2*BIG is an integer < 2^24).
+    const float g2 = (float)(pl->gamma * pl->gamma);
+    float big = 1.0f, bias = 1.0f;
+    if (g2 > 0.0f && std::isfinite(g2)) {
+      int e = 0;
+      (void)std::frexp(g2, &e);                    // g2 = m * 2^e, m in [0.5, 1): ulp(g2) = 2^(e-24)
+      int be = 24 - e;
+      if (be > 126) be = 126;
+      big = std::ldexp(1.0f, be);
+      bias = 1.0f - g2 * big;
+    }
+    p.keep_big = big;
+    p.keep_bias = bias;
+  }
+  {
     const char* ab = std::getenv("SSQ_ABLATE");
     p.ablate = ab ? std::atoi(ab) : 0;
     const char* st = std::getenv("SSQ_STAMPS_PTR");   // diagnostic builds: device buffer address

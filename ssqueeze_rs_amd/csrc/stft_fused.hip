@@ -69,6 +69,8 @@ struct FusedCfg {
   static_assert(LDS_BYTES <= LDS_MAX, "LDS budget");
 };
 
+__device__ __forceinline__ int cvt_round_i32(float x);
+
 // bit casts between T and its integer twin (debug outputs travel through the integer tile)
 template <typename T>
 __device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> as_int(T v) {
@@ -82,7 +84,7 @@ __device__ __forceinline__ T from_int(std::conditional_t<sizeof(T) == 4, int, lo
 }
 template <typename T>
 __device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> to_fixed(T v) {
-  if constexpr (sizeof(T) == 4) return __float2int_rn(v);
+  if constexpr (sizeof(T) == 4) return cvt_round_i32(v);      // floor(v + 1/2): one instruction
   else return __double2ll_rn(v);
 }
 
@@ -127,25 +129,21 @@ __device__ __forceinline__ T frame_allreduce(T v, int lane, T* scratch, int t) {
   return v;
 }
 
-// Hot-path variant of phase_bin (stft_kernels.h) for the TX kernel: same arithmetic, fewer
-// instructions.  Returns keep; `dS` is alpha*dSx (alpha is inside p.two_pi_eff).
-template <typename T>
-__device__ __forceinline__ bool phase_bin_fast(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, int& kk_out) {
-  if constexpr (sizeof(T) == 4) {
-    const float den = S.x * S.x + S.y * S.y;
-    const float num = dS.y * S.x - dS.x * S.y;
-    const float pd = num * __builtin_amdgcn_rcpf(den * p.two_pi_eff);
-    const float w = fabsf((float)i * p.sfs_step - pd);
-    // |Sx| < gamma, or w infinite (:23, :278).  A NaN w can only come from non-finite samples, and
-    // those make the whole column NaN through column_scale, so it may be dropped here.
-    const bool keep = (den >= p.gamma2) && (w <= 3.402823466e+38f);
-    const float u = __builtin_fmaf(w, p.inv_dw, -0.5f);
-    kk_out = (int)fminf(__builtin_ceilf(u), (float)(p.n_freqs - 1));
-    return keep;
-  } else {
-    T w;
-    return phase_bin<T>(p, i, S, dS, w, kk_out);
-  }
+// single-instruction helpers (inline asm: no builtin exists for these forms)
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {   // clamp(a*b + c) to [0,1]; NaN -> 0
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int cvt_floor_i32(float x) {                     // floor(x); NaN -> 0; saturates
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int cvt_round_i32(float x) {                     // floor(x + 0.5); saturates
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 
 // Power-of-two fixed-point scale of a column: 2^e > tot, scale = dw * 2^(FRAC-e), inv = 2^(e-FRAC).
@@ -449,22 +447,53 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         int dstb[9];                                 // byte offset of the destination inside a plane
         T l1 = (T)0;
         const int fl4 = fl * (int)sizeof(T);
+        if constexpr (sizeof(T) == 4) {
+          // fp32 hot path, tuned by the measured op costs (tools/ubench/valu_rate2.hip: compares, selects,
+          // min/max, conversions are half rate): masks by clamped fma instead of compare+select, bin
+          // index by one floor-convert, no select on the destination (a masked-out bin adds 0 anywhere)
+          const float lane_on = EDGE ? (cur[f].valid ? 1.0f : 0.0f) : 1.0f;
+          const float sfs0 = (float)t * p.sfs_step, sfs_q = (float)L * p.sfs_step;
+          const int neg_last = -(p.n_freqs - 1);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const int k = t + L * q;
-          const cpx<T> zk = v[f][q], zn = zp[f][q];
-          const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
-          const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
-          int kk = k;
-          bool keep = true;
-          if (!SSQ_ABL(8)) keep = phase_bin_fast<T>(p, k, S, dS, kk);
-          keep = keep && cur[f].valid && (q < 8 || t == 0);
-          cpx<T> c = LEB ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
-          c.x = keep ? c.x : (T)0;
-          c.y = keep ? c.y : (T)0;
-          cv[q] = c;
-          dstb[q] = __mul24(keep ? kk : 0, PITCH * (int)sizeof(T)) + fl4;   // 24-bit multiply: full rate
-          l1 += fabs(c.x) + fabs(c.y);
+          for (int q = 0; q < 9; ++q) {
+            const cpx<T> zk = v[f][q], zn = zp[f][q];
+            const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+            const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
+            const float den = S.x * S.x + S.y * S.y;
+            const float num = dS.y * S.x - dS.x * S.y;
+            const float pd = num * __builtin_amdgcn_rcpf(den * p.two_pi_eff);
+            const float w = fabsf((sfs0 + (float)q * sfs_q) - pd);            // ssq_stft.rs:33
+            // keep = (|Sx|^2 >= gamma^2) and (w finite)   (ssq_stft.rs:23, :278) as a 0/1 float
+            float m = fma_clamp01(den, p.keep_big, p.keep_bias) * fma_clamp01(w, 0.0f, 1.0f);
+            if (EDGE) m *= lane_on;
+            if (q == 8) m *= (t == 0) ? 1.0f : 0.0f;                           // bin N/2 lives on lane 0 only
+            if (SSQ_ABL(8)) m = lane_on;
+            const cpx<T> c = LEB ? cpx<T>{p.leb_unit * m, 0.0f} : cpx<T>{S.x * m, S.y * m};   // weight (:292-296)
+            cv[q] = c;
+            // kk = ceil(w/dw - 1/2) = -floor(1/2 - w/dw), clamped to the last bin (ssq_stft.rs:280-289)
+            int kneg = cvt_floor_i32(__builtin_fmaf(-w, p.inv_dw, 0.5f));
+            kneg = kneg < neg_last ? neg_last : kneg;
+            dstb[q] = __mul24(kneg, -(PITCH * (int)sizeof(T))) + fl4;
+            l1 += fabsf(c.x) + fabsf(c.y);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const int k = t + L * q;
+            const cpx<T> zk = v[f][q], zn = zp[f][q];
+            const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+            const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
+            int kk = k;
+            T w;
+            bool keep = phase_bin<T>(p, k, S, dS, w, kk);
+            keep = keep && cur[f].valid && (q < 8 || t == 0);
+            cpx<T> c = LEB ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
+            c.x = keep ? c.x : (T)0;
+            c.y = keep ? c.y : (T)0;
+            cv[q] = c;
+            dstb[q] = (keep ? kk : 0) * (PITCH * (int)sizeof(T)) + fl4;
+            l1 += fabs(c.x) + fabs(c.y);
+          }
         }
         SSQ_STAMP(4);
         // fixed-point scatter: every partial sum of this column is bounded by its L1 mass dw*sum|c|;

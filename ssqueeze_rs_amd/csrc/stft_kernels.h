@@ -32,6 +32,7 @@ struct StftDev {
   T inv_alpha;             // dSx = unpacked imaginary channel * inv_alpha (exact: power of two)
   T two_pi_eff;            // 2*pi*alpha when phase_bin is fed alpha*dSx (fused), 2*pi otherwise
   unsigned long long* stamps;  // diagnostic builds only (-DSSQ_STAMPS): per-wave cycle totals per phase
+  float keep_big, keep_bias;   // fp32 TX kernel: keep-mask of |Sx|^2 >= gamma^2 as clamp(den*keep_big + keep_bias)
   int ablate;              // timing experiments only (env SSQ_ABLATE): bit mask of stages to skip; 0 in production
   T leb_unit;              // 1/n_freqs weight of "lebesgue" (ssq_stft.rs:294), without the dw factor
 };
