@@ -28,6 +28,21 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def measured_traffic(B, log2n, n_fft, hop):
+    """HBM bytes per launch from the committed PMC run of this kernel (profiles/r01_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied).  Traffic is per signal, so
+    other batch sizes scale it; other shapes have no measurement -> None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["log2n"], w["n_fft"], w["hop"]) != (log2n, n_fft, hop):
+            return None
+        return int(t["bytes_per_signal"] * B)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def synth_batch(n_distinct, N):
     from oracle.ssq_oracle import synth_signal      # synthetic workload generator only (SURVEY §8d)
     return np.stack([synth_signal(N, b, np.float32) for b in range(n_distinct)])
@@ -191,8 +206,9 @@ def main():
                        "batch_per_gpu": B, "n_signal": N, "n_fft": n_fft, "hop": hop,
                        "n_freqs": n_freqs, "n_frames": n_frames, "parallelism": f"batch-sharded x{n_gpus}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "stft_fused_kernel<float,10>", "kernel_ms_avg": k_avg,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(B, args.log2n, n_fft, hop),
+                         "kernel": "stft_fused_kernel<float,10,true,false,false> (interior tiles; the edge-tile launch of the same pass is inside the timed events)", "kernel_ms_avg": k_avg,
                          "kernel_ms_min": float(np.min(kern_ms)),
                          "alg_bytes_per_launch": B * alg_bytes_per_signal},
             "device": name.value.decode(), "cu_count": cu.value,
