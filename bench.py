@@ -104,9 +104,10 @@ def main():
     if not have_cuda:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     from ssqueeze_rs_amd import _lib
     lib = _lib.load()
@@ -151,7 +152,7 @@ def main():
         _lib.check(lib.ssq_event_create(C.byref(b_)))
         evs.append((a, b_))
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -161,7 +162,7 @@ def main():
         _lib.check(lib.ssq_event_record(b_, stream))
     _lib.check(lib.ssq_stream_sync(stream))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
 
@@ -171,13 +172,13 @@ def main():
         ms = C.c_float(0)
         _lib.check(lib.ssq_event_elapsed_ms(a, b_, C.byref(ms)))
         kern_ms.append(ms.value)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
     gather_ms = None
-    if args.gather and world > 1:
+    if args.gather and use_dist:
         # optional final gather of the Tx shards over xGMI (RCCL); timed separately, never part of `value`
         shard = torch.empty(min(B, 8) * bins_per_signal * 2, device="cuda", dtype=torch.float32)
         outl = torch.empty(world * shard.numel(), device="cuda", dtype=torch.float32)
@@ -226,7 +227,7 @@ def main():
     lib.ssq_dev_free(d_out)
     lib.ssq_stft_plan_destroy(plan)
     lib.ssq_stream_destroy(stream)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -17,7 +17,7 @@
 
 namespace ssq {
 
-constexpr int kTileThreads = 256;
+constexpr int kTileThreads = 512;   // 8 waves per block (one block per CU: the tile takes most of the LDS)
 
 constexpr int pow2_floor(int v) {
   int r = 1;

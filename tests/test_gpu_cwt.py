@@ -180,3 +180,24 @@ def test_ssq_cwt_batch_and_errors():
     a, _ = _rs.ssq_cwt(xb[0], wavelet="nonsense", nv=4)  # unknown wavelet -> gmw (cwt.rs:522)
     b, _ = _rs.ssq_cwt(xb[0], wavelet="gmw", nv=4)
     assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 2e-5)])
+def test_ssq_cwt_large_two_step(dtype, tol):
+    """N = 2^16 (P = 2^17 = 512 x 256 two-step FFT), 64 log scales over [2, N/2]: the C4/C5 code path at a size
+    the oracle finishes in seconds."""
+    N = 1 << 16
+    x = _sig(N, 7, dtype)
+    scales = 2.0 ** np.linspace(1, 15, 64)
+    Tx, f, dbg = _rs.ssq_cwt(x, wavelet="morlet", scales=scales, _debug=True)
+    Tx_o, f_o, im = o.ssq_cwt(x.astype(np.float64), "morlet", scales=scales, return_intermediates=True)
+    assert Tx.shape == (64, N) and np.array_equal(f, f_o)
+    wmax = np.abs(im["Wx"]).max()
+    assert np.abs(dbg["Wx"] - im["Wx"]).max() <= tol * wmax
+    assert np.abs(dbg["dWx"] - im["dWx"]).max() <= tol * np.abs(im["dWx"]).max()
+    keep = dbg["k"] >= 0
+    assert (keep == im["valid"]).mean() >= 0.999
+    both = keep & im["valid"]
+    assert (dbg["k"][both] == im["k"][both]).mean() >= (0.9999 if dtype == np.float64 else 0.99)
+    d = np.abs(Tx.astype(np.complex128).sum(0) - Tx_o.sum(0))
+    assert np.median(d) <= (1e-9 if dtype == np.float64 else 1e-4) * wmax
