@@ -29,6 +29,7 @@
 // The window tables arrive pre-multiplied by 1/2 (so the unpack needs no scaling) and the
 // derivative channel by a power of two alpha (balances the two packed channels); alpha is
 // folded into the 2*pi of the phase transform (StftDev::two_pi_eff).
+#include <cstdlib>
 #include <type_traits>
 #include "fft_core.h"
 #include "stft_kernels.h"
@@ -605,6 +606,249 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// High-occupancy variant for fp32, n_fft = 1024, SSQ_OUT_TX: 16 waves per CU (4 per SIMD) instead of 8.
+// The 8-wave kernel is bound by exposed latency (two waves per SIMD cannot cover the LDS round trips);
+// to fit 16 waves the per-wave LDS row shrinks to HALF a frame and the registers to <= 128:
+//   * exchange 1 goes through the half-size row in two phases (lanes 0-31 write, all read their first
+//     8 values; lanes 32-63 write, all read the other 8) -- the DS unit runs a wave's ops in order;
+//   * exchange 2 is a 4x4 transpose between the four 16-lane rows and the low two bits of the register
+//     index: v_permlane32_swap + v_permlane16_swap, no LDS;
+//   * twiddles come from an LDS copy of the W_1024 table, samples are prefetched one tile ahead.
+// One tile = one frame per wave, so the tile barrier comes once per frame per wave.
+// ---------------------------------------------------------------------------------------------
+struct Hi1024 {
+  static constexpr int N = 1024, L = 64, NF = 513, F = 16, PITCH = 17, W = 16;
+  static constexpr int PLANE = NF * PITCH;
+  static constexpr int TILE_BYTES = (((2 * PLANE + F) * 4 + 15) / 16) * 16;
+  static constexpr int EXH_ELEMS = 512 + 32;               // half a frame, +1 per 16
+  static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
+  static constexpr int TAB_BYTES = N * 8;                   // window table, twiddle table
+  static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
+  static constexpr int FRAC = 30, EMIN = -90;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// 4x4 transpose of R[0..3] across the four 16-lane rows of the wave (one dword per lane per register)
+__device__ __forceinline__ void rows_transpose4(float& r0, float& r1, float& r2, float& r3) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+  auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  r0 = __uint_as_float(c[0]);
+  r1 = __uint_as_float(c[1]);
+  r2 = __uint_as_float(d[0]);
+  r3 = __uint_as_float(d[1]);
+}
+
+template <bool EDGE, bool LEB>
+__global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
+  using H = Hi1024;
+  using T = float;
+  constexpr int N = H::N, L = H::L, NF = H::NF, F = H::F, PITCH = H::PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[H::LDS_BYTES];
+  int* tile_re = reinterpret_cast<int*>(smem);
+  int* tile_im = tile_re + H::PLANE;
+  float* col_scale = reinterpret_cast<float*>(tile_im + H::PLANE);
+  cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES);
+  cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES + H::EXH_BYTES);
+  cpx<T>* tw_lds = win_lds + N;
+
+  const int tid = threadIdx.x;
+  const int t = tid & 63;          // lane = position inside the frame
+  const int fl = tid >> 6;         // wave = frame inside the tile
+  cpx<T>* exch = exch_all + fl * H::EXH_ELEMS;
+
+  for (int i = tid; i < N; i += 1024) {
+    win_lds[i] = p.win2[i];
+    tw_lds[i] = p.tw[i];
+  }
+  for (int i = tid; i < 2 * H::PLANE; i += 1024) tile_re[i] = 0;
+  __syncthreads();
+  if ((long long)blockIdx.x >= p.total_tiles) return;
+
+  const long long n_sig = p.total_tiles / p.tiles_per_signal;
+  long long sig = (long long)(blockIdx.x / (unsigned)p.tiles_per_signal);
+  int jt = (int)(blockIdx.x % (unsigned)p.tiles_per_signal);
+  auto tile_frame0 = [&](int j) { return ((j < p.ta_n) ? p.ta0 + j : p.tb0 + (j - p.ta_n)) * F; };
+  auto load_frame = [&](long long sg, int frame0, T (&xv)[16]) {
+    const int frame = frame0 + fl;
+    const T* xs = p.x + sg * p.n_signal;
+    const long long pos0 = (long long)frame * p.hop - p.pad_left + t;
+    if constexpr (!EDGE) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xv[q] = xs[pos0 + L * q];
+    } else {
+      const bool valid = frame < p.n_frames;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xv[q] = valid ? load_padded(xs, pos0 + L * q, p.n_signal, p.padtype) : 0.0f;
+    }
+  };
+  T xn[16];
+  load_frame(sig, tile_frame0(jt), xn);
+  const cpx<T> twr_unused[3][16] = {};
+
+#pragma unroll 1
+  while (true) {
+    const int frame0 = tile_frame0(jt);
+    const bool valid = EDGE ? (frame0 + fl < p.n_frames) : true;
+    cpx<T> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const cpx<T> wq = win_lds[t + L * q];
+      v[q] = {xn[q] * wq.x, xn[q] * wq.y};
+    }
+    // next tile of this block; prefetch its samples behind this frame's FFT
+    long long nsig = sig;
+    int njt = jt + (int)gridDim.x;
+    while (njt >= p.tiles_per_signal) {
+      njt -= p.tiles_per_signal;
+      ++nsig;
+    }
+    const bool has_next = nsig < n_sig;
+    if (has_next) load_frame(nsig, tile_frame0(njt), xn);
+
+    // ---- pass 0: radix 16 over elements t + 64q ----
+    fft_compute<T, 10, 0, false, false>(v, twr_unused, tw_lds, t);
+    // ---- exchange 1 through the half-size row ----
+    {
+      cpx<T> lo[8];
+      if (t < 32) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) exch[exch_phys(16 * t + u)] = v[u];
+      }
+      frame_sync<false>();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) lo[q] = exch[exch_phys(t + L * q)];
+      frame_sync<false>();
+      if (t >= 32) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) exch[exch_phys(16 * (t - 32) + u)] = v[u];
+      }
+      frame_sync<false>();
+#pragma unroll
+      for (int q = 8; q < 16; ++q) v[q] = exch[exch_phys(t + L * (q - 8))];
+      frame_sync<false>();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = lo[q];
+    }
+    // ---- pass 1: twiddle W_256^(k m), radix 16 ----
+    fft_compute<T, 10, 1, false, false>(v, twr_unused, tw_lds, t);
+    // ---- exchange 2: producer (row m, k), reg u = 4 uh + ul  ->  consumer (row ul, k), reg 4 m + uh ----
+    {
+#pragma unroll
+      for (int uh = 0; uh < 4; ++uh) {
+        rows_transpose4(v[4 * uh + 0].x, v[4 * uh + 1].x, v[4 * uh + 2].x, v[4 * uh + 3].x);
+        rows_transpose4(v[4 * uh + 0].y, v[4 * uh + 1].y, v[4 * uh + 2].y, v[4 * uh + 3].y);
+      }
+      // slot 4*uh + a now holds consumer register q = 4*a + uh: transpose the register indices
+#define SSQ_SWAP(i, j)       \
+  {                          \
+    const cpx<T> t_ = v[i];  \
+    v[i] = v[j];             \
+    v[j] = t_;               \
+  }
+      SSQ_SWAP(1, 4) SSQ_SWAP(2, 8) SSQ_SWAP(3, 12) SSQ_SWAP(6, 9) SSQ_SWAP(7, 13) SSQ_SWAP(11, 14)
+#undef SSQ_SWAP
+    }
+    // ---- pass 2: twiddle W_1024^((t + 64 b) m), four radix-4 butterflies ----
+    fft_compute<T, 10, 2, false, false>(v, twr_unused, tw_lds, t);
+    // lane t now holds Z[t + 64 q]
+
+    // ---- partner Z[N-k] for the bins this lane owns ----
+    cpx<T> zp[9];
+    {
+      const int src = (L - t) & (L - 1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        cpx<T> r;
+        r.x = __shfl(v[15 - q].x, src);
+        r.y = __shfl(v[15 - q].y, src);
+        if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
+        zp[q] = r;
+      }
+      zp[8] = v[8];
+    }
+
+    // ---- unpack, phase transform, bin index, fixed-point scatter (same arithmetic as stft_fused_kernel) ----
+    {
+      cpx<T> cv[9];
+      int dstb[9];
+      T l1 = 0.0f;
+      const int fl4 = fl * 4;
+      const float lane_on = valid ? 1.0f : 0.0f;
+      const float sfs0 = (float)t * p.sfs_step, sfs_q = (float)L * p.sfs_step;
+      const int neg_last = -(p.n_freqs - 1);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const cpx<T> zk = v[q], zn = zp[q];
+        const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
+        const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};
+        const float den = S.x * S.x + S.y * S.y;
+        const float num = dS.y * S.x - dS.x * S.y;
+        const float pd = num * __builtin_amdgcn_rcpf(den * p.two_pi_eff);
+        const float w = fabsf((sfs0 + (float)q * sfs_q) - pd);
+        float m = fma_clamp01(den, p.keep_big, p.keep_bias) * fma_clamp01(w, 0.0f, 1.0f);
+        if (EDGE) m *= lane_on;
+        if (q == 8) m *= (t == 0) ? 1.0f : 0.0f;
+        const cpx<T> c = LEB ? cpx<T>{p.leb_unit * m, 0.0f} : cpx<T>{S.x * m, S.y * m};
+        cv[q] = c;
+        int kneg = cvt_floor_i32(__builtin_fmaf(-w, p.inv_dw, 0.5f));
+        kneg = kneg < neg_last ? neg_last : kneg;
+        dstb[q] = __mul24(kneg, -(PITCH * 4)) + fl4;
+        l1 += fabsf(c.x) + fabsf(c.y);
+      }
+      const T tot = frame_allreduce<T, L, false>(l1, t, nullptr, t) * p.dw;
+      T scale, inv_scale;
+      column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
+      if (t == 0 && valid) col_scale[fl] = inv_scale;
+      char* pre = reinterpret_cast<char*>(tile_re);
+      char* pim = reinterpret_cast<char*>(tile_im);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        atomicAdd(reinterpret_cast<unsigned*>(pre + dstb[q]), (unsigned)cvt_round_i32(cv[q].x * scale));
+        if (!LEB) atomicAdd(reinterpret_cast<unsigned*>(pim + dstb[q]), (unsigned)cvt_round_i32(cv[q].y * scale));
+      }
+      if (t == 0) {
+        atomicAdd(reinterpret_cast<unsigned*>(pre + dstb[8]), (unsigned)cvt_round_i32(cv[8].x * scale));
+        if (!LEB) atomicAdd(reinterpret_cast<unsigned*>(pim + dstb[8]), (unsigned)cvt_round_i32(cv[8].y * scale));
+      }
+    }
+    __syncthreads();
+
+    // ---- tile read-out: thread -> (frame f, rows k0 + 64 j) ----
+    {
+      constexpr int RSTEP = 1024 / F;                       // 64 rows per sweep
+      const int f = tid % F;
+      const int k0 = tid / F;
+      cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0 + f + (long long)k0 * p.n_frames;
+      const long long gstep = (long long)RSTEP * p.n_frames;
+      const bool fvalid = EDGE ? (frame0 + f < p.n_frames) : true;
+      const T sc = col_scale[f];
+      int* tr = tile_re + k0 * PITCH + f;
+      int* ti = tile_im + k0 * PITCH + f;
+      constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
+#pragma unroll
+      for (int j = 0; j < NFULL; ++j) {
+        const int ire = tr[j * RSTEP * PITCH], iim = ti[j * RSTEP * PITCH];
+        tr[j * RSTEP * PITCH] = 0;
+        ti[j * RSTEP * PITCH] = 0;
+        if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
+      }
+      if (k0 + NFULL * RSTEP < NF) {
+        const int ire = tr[NFULL * RSTEP * PITCH], iim = ti[NFULL * RSTEP * PITCH];
+        tr[NFULL * RSTEP * PITCH] = 0;
+        ti[NFULL * RSTEP * PITCH] = 0;
+        if (fvalid) og[NFULL * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
+      }
+    }
+    __syncthreads();
+    if (!has_next) break;
+    sig = nsig;
+    jt = njt;
+  }
+}
+
 // ------------------------------------------------------------------ launch ----
 template <typename T>
 bool fused_supported(int n_fft) {
@@ -645,6 +889,27 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
     long long blocks = (long long)cu_count * per_cu;
     if (blocks > p.total_tiles) blocks = p.total_tiles;
     const dim3 g((unsigned)blocks), b(C::W * 64);
+    if constexpr (sizeof(T) == 4 && LOGN == 10) {
+      static const bool hiocc = []() {
+        const char* e = std::getenv("SSQ_HIOCC");
+        return e ? std::atoi(e) != 0 : true;
+      }();
+      if (hiocc && p.out_kind == 0) {
+        long long nb = cu_count;                      // one 1024-thread block per CU
+        if (nb > p.total_tiles) nb = p.total_tiles;
+        const dim3 gh((unsigned)nb), bh(1024);
+        if (p.squeezing == 1) {
+          if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, true>), gh, bh, 0, stream, p);
+          else hipLaunchKernelGGL((stft_tx1024_kernel<false, true>), gh, bh, 0, stream, p);
+        } else {
+          if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false>), gh, bh, 0, stream, p);
+          else hipLaunchKernelGGL((stft_tx1024_kernel<false, false>), gh, bh, 0, stream, p);
+        }
+        const hipError_t eh = hipGetLastError();
+        if (eh != hipSuccess) return eh;
+        continue;
+      }
+    }
     if (p.out_kind == 0 && p.squeezing == 1) {
       if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, true>), g, b, 0, stream, p);
       else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false, true>), g, b, 0, stream, p);
