@@ -31,7 +31,10 @@ __device__ __forceinline__ void butterflies(cpx<T> (&v)[16], std::integer_sequen
 }
 
 // Twiddle multiply (P > 0) + in-register butterflies of Stockham pass P (see ssq_common.h pass tables).
-template <typename T, int LOGN, int P, bool INV, bool TW_REGS>
+// TW_COMPACT: `tw_tab` is this pass's own table laid out [m][k] (k = position inside the sub-transform,
+// NS entries per m), so that the lanes of one read touch consecutive elements (no LDS bank conflicts);
+// otherwise it is the full W_N table indexed k*m*(N/(NS*R)).
+template <typename T, int LOGN, int P, bool INV, bool TW_REGS, bool TW_COMPACT = false>
 __device__ __forceinline__ void fft_compute(cpx<T> (&v)[16], const cpx<T> (&twr)[3][16],
                                             const cpx<T>* __restrict__ tw_tab, int t) {
   constexpr int N = 1 << LOGN, L = N / 16;
@@ -46,7 +49,7 @@ __device__ __forceinline__ void fft_compute(cpx<T> (&v)[16], const cpx<T> (&twr)
           w = twr[P - 1][b + m * NB];
         } else {
           const int k = (t + L * b) & (NS - 1);
-          w = tw_tab[k * m * (N / (NS * R))];
+          w = TW_COMPACT ? tw_tab[m * NS + k] : tw_tab[k * m * (N / (NS * R))];
         }
         if (INV) w.y = -w.y;
         v[b + m * NB] = cmul(v[b + m * NB], w);

@@ -623,7 +623,7 @@ struct Hi1024 {
   static constexpr int TILE_BYTES = (((2 * PLANE + F) * 4 + 15) / 16) * 16;
   static constexpr int EXH_ELEMS = 512 + 32;               // half a frame, +1 per 16
   static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
-  static constexpr int TAB_BYTES = N * 8;                   // window table, twiddle table
+  static constexpr int TAB_BYTES = N * 8;                   // window table; twiddle tables [16][16] + [3][256] (+pad)
   static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
   static constexpr int FRAC = 30, EMIN = -90;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -652,17 +652,17 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
   float* col_scale = reinterpret_cast<float*>(tile_im + H::PLANE);
   cpx<T>* exch_all = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES);
   cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES + H::EXH_BYTES);
-  cpx<T>* tw_lds = win_lds + N;
+  cpx<T>* tw1 = win_lds + N;        // pass 1: [m = 0..15][k = 0..15]   W_256^(k m)
+  cpx<T>* tw2 = tw1 + 256;          // pass 2: [m = 0..2][j = 0..255]   W_1024^(j (m+1))  (row m+1 of the compact layout)
 
   const int tid = threadIdx.x;
   const int t = tid & 63;          // lane = position inside the frame
   const int fl = tid >> 6;         // wave = frame inside the tile
   cpx<T>* exch = exch_all + fl * H::EXH_ELEMS;
 
-  for (int i = tid; i < N; i += 1024) {
-    win_lds[i] = p.win2[i];
-    tw_lds[i] = p.tw[i];
-  }
+  for (int i = tid; i < N; i += 1024) win_lds[i] = p.win2[i];
+  if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
+  for (int i = tid; i < 768; i += 1024) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
   for (int i = tid; i < 2 * H::PLANE; i += 1024) tile_re[i] = 0;
   __syncthreads();
   if ((long long)blockIdx.x >= p.total_tiles) return;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
     if (has_next) load_frame(nsig, tile_frame0(njt), xn);
 
     // ---- pass 0: radix 16 over elements t + 64q ----
-    fft_compute<T, 10, 0, false, false>(v, twr_unused, tw_lds, t);
+    fft_compute<T, 10, 0, false, false>(v, twr_unused, tw1, t);
     // ---- exchange 1 through the half-size row ----
     {
       cpx<T> lo[8];
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       for (int q = 0; q < 8; ++q) v[q] = lo[q];
     }
     // ---- pass 1: twiddle W_256^(k m), radix 16 ----
-    fft_compute<T, 10, 1, false, false>(v, twr_unused, tw_lds, t);
+    fft_compute<T, 10, 1, false, false, true>(v, twr_unused, tw1, t);
     // ---- exchange 2: producer (row m, k), reg u = 4 uh + ul  ->  consumer (row ul, k), reg 4 m + uh ----
     {
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
 #undef SSQ_SWAP
     }
     // ---- pass 2: twiddle W_1024^((t + 64 b) m), four radix-4 butterflies ----
-    fft_compute<T, 10, 2, false, false>(v, twr_unused, tw_lds, t);
+    fft_compute<T, 10, 2, false, false, true>(v, twr_unused, tw2 - 256, t);   // compact index m*256 + j, m = 1..3
     // lane t now holds Z[t + 64 q]
 
     // ---- partner Z[N-k] for the bins this lane owns ----

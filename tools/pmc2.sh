@@ -24,7 +24,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "stft_fused" in r["Kernel_Name"] or "cwt_" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("stft_fused", "stft_tx1024", "cwt_")):
             agg[(r["Kernel_Name"][:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
     for (k, c), v in sorted(agg.items()):
