@@ -23,6 +23,8 @@ struct ssq_cwt_plan {
   void* d_psih = nullptr;      // [na][P/2+1] T
   void* d_tw1 = nullptr;       // W_{P1}^i
   void* d_tw2 = nullptr;       // W_{P2}^i
+  void* d_twz = nullptr;       // W_Q^i at [Q, 2Q) for Q = 16 .. 2048 (mode Z)
+  std::vector<int> zoom_logq;  // per scale: log2 Q of the band-limited single-pass path, 0 = two-step path
   void* d_twhi = nullptr;      // W_P^(i<<12)
   void* d_twlo = nullptr;      // W_P^i, i < 4096
   void* d_scale_l1 = nullptr;  // [na] 1/P
@@ -34,6 +36,16 @@ struct ssq_cwt_plan {
 namespace {
 
 const long double kPI = 3.14159265358979323846264338327950288L;
+constexpr long long kZoomMaxQ = 2048;   // longest single-pass (mode Z) transform: C = 8 rows of it fit the LDS in fp32
+
+// Smallest w beyond which the wavelet table entry is exactly zero in T (the table is evaluated in fp64 and
+// rounded once to T: csrc/cwt_kernels.hip::wavelet_table_kernel), with margin.
+//   morlet (cwt.rs:497-520): exp(-(w-6)^2/2) underflows T    -> fp32 (1.4e-45): |w-6| > 14.4 ; fp64: |w-6| > 38.6
+//   gmw    (cwt.rs:522-542): exp(60 ln w - w^3) underflows T -> fp32: w > 6.0 ; fp64: w > 9.6
+double wavelet_support(int wavelet, int dtype) {
+  if (wavelet == SSQ_WAVELET_MORLET) return dtype == SSQ_F32 ? 21.0 : 46.0;
+  return dtype == SSQ_F32 ? 6.5 : 10.0;
+}
 
 template <typename T>
 int upload_tw(void** dst, long long n, long long P_total, long long stride) {
@@ -53,6 +65,16 @@ int build_tables(ssq_cwt_plan* pl) {
   const long long P1 = 1LL << pl->log_p1, P2 = 1LL << pl->log_p2;
   if (int rc = upload_tw<T>(&pl->d_tw1, P1, P1, 1)) return rc;
   if (int rc = upload_tw<T>(&pl->d_tw2, P2, P2, 1)) return rc;
+  if (pl->two_step) {
+    std::vector<cpx<T>> hz(2 * kZoomMaxQ);
+    for (long long Q = 16; Q <= kZoomMaxQ; Q *= 2)
+      for (long long i = 0; i < Q; ++i) {
+        const long double ang = 2.0L * kPI * (long double)i / (long double)Q;
+        hz[(size_t)(Q + i)] = {(T)cosl(ang), (T)(-sinl(ang))};
+      }
+    SSQ_HIP(hipMalloc(&pl->d_twz, sizeof(cpx<T>) * hz.size()));
+    SSQ_HIP(hipMemcpy(pl->d_twz, hz.data(), sizeof(cpx<T>) * hz.size(), hipMemcpyHostToDevice));
+  }
   const long long nlo = pl->P < 4096 ? pl->P : 4096;
   const long long nhi = pl->P < 4096 ? 1 : pl->P / 4096;
   if (int rc = upload_tw<T>(&pl->d_twlo, nlo, pl->P, 1)) return rc;
@@ -166,14 +188,33 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
     SSQ_HIP(launch_cwt_tile<T>(CWT_INV_S, p, st));
     return 0;
   }
-  for (int s0 = 0; s0 < pl->na; s0 += pl->chunk) {
-    const int ns = (pl->na - s0 < pl->chunk) ? pl->na - s0 : pl->chunk;
-    p.scale0 = s0;
-    p.n_transforms = ns * p.n_kinds;
-    p.tw_m = (const cpx<T>*)pl->d_tw1;
-    SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
-    p.tw_m = (const cpx<T>*)pl->d_tw2;
-    SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+  // runs of consecutive scales on the same path: band-limited ones (mode Z, grouped by Q) in one launch per run,
+  // the others through the two-step transform in chunks whose ybuf stays inside the Infinity Cache
+  int s0 = 0;
+  while (s0 < pl->na) {
+    const int lq = pl->zoom_logq[(size_t)s0];
+    int s1 = s0 + 1;
+    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq) ++s1;
+    if (lq > 0) {
+      CwtDev<T> z = p;
+      z.scale0 = s0;
+      z.n_transforms = (s1 - s0) * p.n_kinds;
+      z.log_p2 = lq;
+      z.log_p1 = pl->logP - lq;
+      z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
+      SSQ_HIP(launch_cwt_tile<T>(CWT_INV_Z, z, st));
+    } else {
+      for (int c0 = s0; c0 < s1; c0 += pl->chunk) {
+        const int ns = (s1 - c0 < pl->chunk) ? s1 - c0 : pl->chunk;
+        p.scale0 = c0;
+        p.n_transforms = ns * p.n_kinds;
+        p.tw_m = (const cpx<T>*)pl->d_tw1;
+        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
+        p.tw_m = (const cpx<T>*)pl->d_tw2;
+        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+      }
+    }
+    s0 = s1;
   }
   return 0;
 }
@@ -290,6 +331,20 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   if (ch < 1) ch = 1;
   if (ch > (na > 0 ? na : 1)) ch = (na > 0 ? na : 1);
   pl->chunk = (int)ch;
+  pl->zoom_logq.assign((size_t)na, 0);
+  if (pl->two_step) {
+    const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
+    const double wmax = wavelet_support(wavelet, dtype);
+    for (int64_t i = 0; i < na; ++i) {
+      const double a = scales[i];
+      if (!(a > 0.0) || !std::isfinite(a)) continue;
+      const double kb = wmax / (a * h) + 2.0;                        // psih_i[k] == 0 for k >= kb
+      if (kb > (double)kZoomMaxQ) continue;
+      int lq = 4;
+      while ((double)(1LL << lq) < kb) ++lq;
+      pl->zoom_logq[(size_t)i] = lq;
+    }
+  }
   int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
   if (rc) {
     ssq_cwt_plan_destroy(pl);
@@ -304,6 +359,7 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_psih);
   hipFree(pl->d_tw1);
   hipFree(pl->d_tw2);
+  hipFree(pl->d_twz);
   hipFree(pl->d_twhi);
   hipFree(pl->d_twlo);
   hipFree(pl->d_scale_l1);

@@ -11,7 +11,9 @@ enum CwtMode {
   CWT_FWD_S = 2,   // P <= 4096: padded real signal -> xh in one step
   CWT_INV_A = 3,   // xh * psih (* i*xi/dt) -> column iFFTs (+ conj twiddle) -> ybuf
   CWT_INV_B = 4,   // ybuf rows -> row iFFTs -> Wx / dWx (scaled, unpadded)
-  CWT_INV_S = 5    // P <= 4096: xh * psih -> Wx / dWx in one step
+  CWT_INV_S = 5,   // P <= 4096: xh * psih -> Wx / dWx in one step
+  CWT_INV_Z = 6    // band-limited scale (psih == 0 for k >= Q = 2^log_p2): P = D*Q, one length-Q iFFT per residue
+                   // d = n mod D of the spectrum times W_P^(-k d); no ybuf pass at all
 };
 
 template <typename T>

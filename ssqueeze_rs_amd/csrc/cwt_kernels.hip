@@ -7,6 +7,10 @@
 //   step A: C adjacent columns of the [P1][P2] view per block, length-P1 FFTs in LDS, times W_P^(c*k1)
 //   step B: C adjacent rows per block, length-P2 FFTs in LDS, output transposed in LDS so that global
 //           stores are C-element contiguous segments (natural order, unpadded: cwt.rs:108-129)
+// Band-limited scales skip step A altogether (mode Z): when psih_s[k] == 0 for all k >= Q (Q <= 2048 a power
+// of two, D = P/Q), x[D m + d] = sum_{k<Q} (X[k] e^{+2 pi i k d/P}) e^{+2 pi i k m/Q} is one length-Q iFFT per
+// residue d; a block takes C adjacent residues, so it stores the same C-element segments as step B and the
+// only HBM traffic of the scale is its output.
 // The wavelet multiply (cwt.rs:238-240, :275-277) is fused into step A's load and the 1/P and
 // sqrt(scale) normalisation (cwt.rs:251-262) into step B's store; xh (16.8 MB at P = 2^21) is
 // re-read by every scale and stays resident in the 256 MB Infinity Cache.
@@ -48,15 +52,17 @@ __device__ __forceinline__ cpx<T> conj_if(cpx<T> v, bool inv) {
   return v;
 }
 
-// element n of the spectrum fed to an inverse transform: xh[n] * psih_s[n] (* i*xi_n/dt)
+// element n of the spectrum fed to an inverse transform: xh[n] * psih_s[n] (* i*xi_n/dt).
+// The loads are unconditional (clamped index) so that a batch of them can be in flight together.
 template <typename T>
 __device__ __forceinline__ cpx<T> load_spectrum(const CwtDev<T>& p, int tr, long long n) {
   const long long half = p.P >> 1;
-  if (n > half) return {(T)0, (T)0};                    // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536)
+  const long long nn = n > half ? half : n;
   const int s = p.scale0 + tr / p.n_kinds;
   const int kind = tr % p.n_kinds;
-  const T psi = p.psih[(long long)s * (half + 1) + n];
-  const cpx<T> xv = p.xh[n];
+  T psi = p.psih[(long long)s * (half + 1) + nn];
+  const cpx<T> xv = p.xh[nn];
+  if (n > half) psi = (T)0;                             // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536)
   cpx<T> v = {xv.x * psi, xv.y * psi};                  // cwt.rs:238-240
   if (kind == 1) {                                      // * Complex(0, xi/dt)  cwt.rs:205-208
     const T xi = (T)n * p.xi_step;
@@ -65,69 +71,100 @@ __device__ __forceinline__ cpx<T> load_spectrum(const CwtDev<T>& p, int tr, long
   return v;
 }
 
+// where transform tr of this launch stores its time samples, and the factor it applies (cwt.rs:251-262)
 template <typename T>
-__device__ __forceinline__ void store_time(const CwtDev<T>& p, int tr, long long n, cpx<T> v) {
+struct TimeDst {
+  cpx<T>* row;
+  T sc;
+};
+template <typename T>
+__device__ __forceinline__ TimeDst<T> time_dst(const CwtDev<T>& p, int tr) {
   const int s = p.scale0 + tr / p.n_kinds;
-  const int kind = tr % p.n_kinds;
-  const T sc = p.out_scale[s];
-  v = {v.x * sc, v.y * sc};
-  cpx<T>* dst = kind ? p.dWx : p.Wx;
+  cpx<T>* dst = (tr % p.n_kinds) ? p.dWx : p.Wx;
+  return {dst + (long long)s * p.cols, p.out_scale[s]};
+}
+template <typename T>
+__device__ __forceinline__ void store_time(const CwtDev<T>& p, const TimeDst<T>& d, long long n, cpx<T> v) {
+  v = {v.x * d.sc, v.y * d.sc};
   if (p.rpadded) {
-    dst[(long long)s * p.P + n] = v;
+    d.row[n] = v;
   } else if (n >= p.n1 && n < p.n1 + p.n_signal) {      // cwt.rs:115
-    dst[(long long)s * p.n_signal + (n - p.n1)] = v;
+    d.row[n - p.n1] = v;
   }
 }
 
-template <typename T, int LOGM>
-__global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p, int mode) {
+// W_P^r from the split table (forward sign), r < P
+template <typename T>
+__device__ __forceinline__ cpx<T> twiddle_P(const CwtDev<T>& p, long long r) {
+  return cmul(p.tw_hi[r >> 12], p.tw_lo[r & 4095]);
+}
+
+// One tile = C transforms of length M in LDS.  MODE is a compile-time CwtMode: every phase is straight-line code
+// over batches of U elements per thread, so U global loads (or stores) are in flight per thread instead of one.
+template <typename T, int LOGM, int MODE>
+__global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
   using K = TileCfg<T, LOGM>;
   constexpr int M = K::M, L = K::L, C = K::C, ROWP = K::ROWP;
   constexpr bool TW_REGS = (sizeof(T) == 4);
+  constexpr bool inv = MODE >= CWT_INV_A;
+  constexpr bool stepA = (MODE == CWT_FWD_A || MODE == CWT_INV_A);
+  constexpr bool stepB = (MODE == CWT_FWD_B || MODE == CWT_INV_B);
+  constexpr bool stepZ = (MODE == CWT_INV_Z);
+  static_assert((C * M) % kTileThreads == 0, "whole sweeps");
+  constexpr int PER = C * M / kTileThreads;             // elements per thread and phase
+  constexpr int U = PER < 8 ? PER : 8;                  // batch
+  static_assert(PER % U == 0, "whole batches");
   __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS_BYTES];
   cpx<T>* rows = reinterpret_cast<cpx<T>*>(smem);
 
   const int tid = threadIdx.x;
   const int tr = blockIdx.y;
   const long long tile = blockIdx.x;
-  const bool inv = mode >= CWT_INV_A;
   const long long P2 = 1LL << p.log_p2;
   const long long P1 = 1LL << p.log_p1;
-  const bool stepA = (mode == CWT_FWD_A || mode == CWT_INV_A);
-  const bool stepB = (mode == CWT_FWD_B || mode == CWT_INV_B);
+  const long long t0 = tile * C;                        // first column (A) / row (B) / residue (Z) / transform (S)
 
   // ---------------- load (conjugated for inverse transforms) ----------------
-  if (stepA) {
-    const long long c0 = tile * C;
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int c = e % C, r = e / C;
-      const long long n = (long long)r * P2 + c0 + c;
-      cpx<T> v;
-      if (mode == CWT_FWD_A) {
-        v = {load_padded(p.x, n - p.n1, p.n_signal, p.padtype), (T)0};
-      } else {
-        v = conj_if(load_spectrum(p, tr, n), true);
-      }
-      rows[c * ROWP + exch_phys(r)] = v;
+  // element e of the tile -> its LDS slot; A walks columns fastest (C-element global segments), the others walk
+  // the transform index fastest
+  auto slot_of = [&](int e) {
+    if constexpr (stepA) return (e % C) * ROWP + exch_phys(e / C);
+    else return (e / M) * ROWP + exch_phys(e % M);
+  };
+  auto fetch = [&](int e) -> cpx<T> {
+    if constexpr (MODE == CWT_FWD_A) {
+      const long long n = (long long)(e / C) * P2 + t0 + (e % C);
+      return {load_padded(p.x, n - p.n1, p.n_signal, p.padtype), (T)0};
+    } else if constexpr (MODE == CWT_INV_A) {
+      const long long n = (long long)(e / C) * P2 + t0 + (e % C);
+      return conj_if(load_spectrum(p, tr, n), true);
+    } else if constexpr (stepB) {
+      // step A already left it conjugated
+      return p.ybuf[(long long)tr * p.P + (t0 + e / M) * P2 + (e % M)];
+    } else if constexpr (stepZ) {
+      const int k = e % M;
+      long long d = t0 + e / M;
+      const bool live = d < P1;                          // D < C: partial tile
+      if (!live) d = 0;
+      const cpx<T> w = twiddle_P(p, (long long)k * d);   // k d < Q D = P;  W_P^(k d) = conj(e^{+2 pi i k d/P})
+      cpx<T> v = cmul(conj_if(load_spectrum(p, tr, k), true), w);
+      if (!live) v = {(T)0, (T)0};
+      return v;
+    } else {
+      const int m = e % M;
+      const long long trc = t0 + e / M;
+      if (trc >= p.n_transforms) return {(T)0, (T)0};
+      if constexpr (MODE == CWT_FWD_S) return {load_padded(p.x, (long long)m - p.n1, p.n_signal, p.padtype), (T)0};
+      else return conj_if(load_spectrum(p, (int)trc, m), true);
     }
-  } else if (stepB) {
-    const long long r0 = tile * C;
-    const cpx<T>* __restrict__ src = p.ybuf + (long long)tr * p.P + r0 * P2;
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int m = e % M, c = e / M;
-      rows[c * ROWP + exch_phys(m)] = src[(long long)c * P2 + m];   // step A already left it conjugated
-    }
-  } else {
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int m = e % M, c = e / M;
-      const long long trc = tile * C + c;
-      cpx<T> v = {(T)0, (T)0};
-      if (trc < p.n_transforms) {
-        if (mode == CWT_FWD_S) v = {load_padded(p.x, (long long)m - p.n1, p.n_signal, p.padtype), (T)0};
-        else v = conj_if(load_spectrum(p, (int)trc, m), true);
-      }
-      rows[c * ROWP + exch_phys(m)] = v;
-    }
+  };
+#pragma unroll 1
+  for (int i0 = 0; i0 < PER; i0 += U) {
+    cpx<T> buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = fetch(tid + (i0 + u) * kTileThreads);
+#pragma unroll
+    for (int u = 0; u < U; ++u) rows[slot_of(tid + (i0 + u) * kTileThreads)] = buf[u];
   }
   __syncthreads();
 
@@ -167,58 +204,84 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p, int
   __syncthreads();
 
   // ---------------- store ----------------
-  if (stepA) {
-    const long long c0 = tile * C;
-    cpx<T>* __restrict__ dst = p.ybuf + (long long)tr * p.P;
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int c = e % C, k1 = e / C;
-      const long long col = c0 + c;
-      const long long r = col * k1;                          // < P1*P2 = P: no reduction needed
-      const cpx<T> w = cmul(p.tw_hi[r >> 12], p.tw_lo[r & 4095]);   // W_P^r (forward sign)
-      // data is conj(true value) for inverse transforms; conj(y * conj(W)) = conj(y) * W
-      dst[(long long)k1 * P2 + col] = cmul(rows[c * ROWP + exch_phys(k1)], w);
+  // A: element (column c fastest, k1): ybuf[k1][col] = y * W_P^(col k1).  The data is conj(true value) for inverse
+  //    transforms and conj(y conj(W)) = conj(y) W, so the forward twiddle serves both directions.
+  // B / Z: element (row / residue c fastest, k2): n = t0 + c + P1 k2, natural order (Z: n = d + D m)
+  TimeDst<T> td = {nullptr, (T)0};
+  if constexpr (MODE == CWT_INV_B || MODE == CWT_INV_Z) td = time_dst(p, tr);
+#pragma unroll 1
+  for (int i0 = 0; i0 < PER; i0 += U) {
+    cpx<T> buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + (i0 + u) * kTileThreads;
+      if constexpr (stepA) {
+        const int c = e % C, k1 = e / C;
+        const long long col = t0 + c;
+        buf[u] = cmul(rows[c * ROWP + exch_phys(k1)], twiddle_P(p, col * k1));   // col k1 < P1 P2 = P
+      } else if constexpr (stepB || stepZ) {
+        buf[u] = conj_if(rows[(e % C) * ROWP + exch_phys(e / C)], inv);
+      } else {
+        buf[u] = conj_if(rows[(e / M) * ROWP + exch_phys(e % M)], inv);
+      }
     }
-  } else if (stepB) {
-    const long long r0 = tile * C;
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int c = e % C, k2 = e / C;
-      const long long n = r0 + c + P1 * k2;
-      const cpx<T> v = conj_if(rows[c * ROWP + exch_phys(k2)], inv);
-      if (mode == CWT_FWD_B) p.xh[n] = v;
-      else store_time(p, tr, n, v);
-    }
-  } else {
-    for (int e = tid; e < C * M; e += kTileThreads) {
-      const int m = e % M, c = e / M;
-      const long long trc = tile * C + c;
-      if (trc >= p.n_transforms) continue;
-      const cpx<T> v = conj_if(rows[c * ROWP + exch_phys(m)], inv);
-      if (mode == CWT_FWD_S) p.xh[m] = v;
-      else store_time(p, (int)trc, m, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + (i0 + u) * kTileThreads;
+      if constexpr (stepA) {
+        const int c = e % C, k1 = e / C;
+        p.ybuf[(long long)tr * p.P + (long long)k1 * P2 + t0 + c] = buf[u];
+      } else if constexpr (stepB || stepZ) {
+        const int c = e % C, k2 = e / C;
+        if (stepZ && t0 + c >= P1) continue;
+        const long long n = t0 + c + P1 * k2;
+        if constexpr (MODE == CWT_FWD_B) p.xh[n] = buf[u];
+        else store_time(p, td, n, buf[u]);
+      } else {
+        const int m = e % M;
+        const long long trc = t0 + e / M;
+        if (trc >= p.n_transforms) continue;
+        if constexpr (MODE == CWT_FWD_S) p.xh[m] = buf[u];
+        else store_time(p, time_dst(p, (int)trc), m, buf[u]);
+      }
     }
   }
 }
 
-template <typename T, int LOGM>
-static hipError_t launch_tile_one(int mode, const CwtDev<T>& p, hipStream_t stream) {
+template <typename T, int LOGM, int MODE>
+static hipError_t launch_tile_mode(const CwtDev<T>& p, hipStream_t stream) {
   using K = TileCfg<T, LOGM>;
   dim3 grid;
-  if (mode == CWT_FWD_A || mode == CWT_INV_A) {
+  if (MODE == CWT_FWD_A || MODE == CWT_INV_A) {
     grid = dim3((unsigned)(((1LL << p.log_p2) + K::C - 1) / K::C), (unsigned)p.n_transforms, 1);
-  } else if (mode == CWT_FWD_B || mode == CWT_INV_B) {
+  } else if (MODE == CWT_FWD_B || MODE == CWT_INV_B || MODE == CWT_INV_Z) {
     grid = dim3((unsigned)(((1LL << p.log_p1) + K::C - 1) / K::C), (unsigned)p.n_transforms, 1);
   } else {
     grid = dim3((unsigned)((p.n_transforms + K::C - 1) / K::C), 1, 1);
   }
-  hipLaunchKernelGGL((cwt_tile_kernel<T, LOGM>), grid, dim3(kTileThreads), 0, stream, p, mode);
+  hipLaunchKernelGGL((cwt_tile_kernel<T, LOGM, MODE>), grid, dim3(kTileThreads), 0, stream, p);
   return hipGetLastError();
+}
+
+template <typename T, int LOGM>
+static hipError_t launch_tile_one(int mode, const CwtDev<T>& p, hipStream_t stream) {
+  switch (mode) {
+    case CWT_FWD_A: return launch_tile_mode<T, LOGM, CWT_FWD_A>(p, stream);
+    case CWT_FWD_B: return launch_tile_mode<T, LOGM, CWT_FWD_B>(p, stream);
+    case CWT_FWD_S: return launch_tile_mode<T, LOGM, CWT_FWD_S>(p, stream);
+    case CWT_INV_A: return launch_tile_mode<T, LOGM, CWT_INV_A>(p, stream);
+    case CWT_INV_B: return launch_tile_mode<T, LOGM, CWT_INV_B>(p, stream);
+    case CWT_INV_S: return launch_tile_mode<T, LOGM, CWT_INV_S>(p, stream);
+    case CWT_INV_Z: return launch_tile_mode<T, LOGM, CWT_INV_Z>(p, stream);
+  }
+  return hipErrorInvalidValue;
 }
 
 template <typename T>
 hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream) {
   int logm;
   if (mode == CWT_FWD_A || mode == CWT_INV_A) logm = p.log_p1;
-  else if (mode == CWT_FWD_B || mode == CWT_INV_B) logm = p.log_p2;
+  else if (mode == CWT_FWD_B || mode == CWT_INV_B || mode == CWT_INV_Z) logm = p.log_p2;
   else logm = p.log_p1;
   switch (logm) {
     case 4: return launch_tile_one<T, 4>(mode, p, stream);
@@ -299,7 +362,7 @@ __global__ void cwt_naive_inv_kernel(CwtDev<T> p) {
     sr += (double)v.x * c - (double)v.y * s;
     si += (double)v.x * s + (double)v.y * c;
   }
-  store_time(p, tr, n, cpx<T>{(T)sr, (T)si});
+  store_time(p, time_dst(p, tr), n, cpx<T>{(T)sr, (T)si});
 }
 
 template <typename T>
@@ -322,9 +385,23 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.N) return;
   const T two_pi = (T)(2.0 * 3.14159265358979323846);
-  for (int i = 0; i < p.na; ++i) {
+  const cpx<T>* __restrict__ Wxp = p.Wx + j;
+  const cpx<T>* __restrict__ dWxp = p.dWx + j;
+  constexpr int UN = 8;                                  // scales whose Wx / dWx loads are in flight together
+  for (int i0 = 0; i0 < p.na; i0 += UN) {
+  cpx<T> Wb[UN], dWb[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
+    Wb[u] = Wxp[(long long)ii * p.N];
+    dWb[u] = dWxp[(long long)ii * p.N];
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int i = i0 + u;
+    if (i >= p.na) break;
     const long long o = (long long)i * p.N + j;
-    const cpx<T> Wv = p.Wx[o], dW = p.dWx[o];
+    const cpx<T> Wv = Wb[u], dW = dWb[u];
     T w;
     bool small;
     if constexpr (sizeof(T) == 4) {
@@ -366,6 +443,7 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
       }
       p.Tx[d] = acc;
     }
+  }
   }
 }
 
