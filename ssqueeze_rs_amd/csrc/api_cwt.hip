@@ -2,6 +2,7 @@
 // Replaces the PyO3 functions `cwt` / `cwt_simd` (rust/src/spectral/cwt.rs:46-144,
 // cwt_simd.rs:52-150) and `ssq_cwt` (rust/src/spectral/ssq_cwt.rs:244-493).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,7 +25,11 @@ struct ssq_cwt_plan {
   void* d_tw1 = nullptr;       // W_{P1}^i
   void* d_tw2 = nullptr;       // W_{P2}^i
   void* d_twz = nullptr;       // W_Q^i at [Q, 2Q) for Q = 16 .. 2048 (mode Z)
+  void* d_f2a = nullptr;       // step A: [P1][C] W_P^(c k1)
+  void* d_f2z[13] = {};        // mode Z, per log2 Q: [C][Q] W_P^(c k)
   std::vector<int> zoom_logq;  // per scale: log2 Q of the band-limited single-pass path, 0 = two-step path
+  std::vector<int> band;       // per scale: psih_s[k] == 0 for k >= band
+  int* d_band = nullptr;
   void* d_twhi = nullptr;      // W_P^(i<<12)
   void* d_twlo = nullptr;      // W_P^i, i < 4096
   void* d_scale_l1 = nullptr;  // [na] 1/P
@@ -66,6 +71,26 @@ int build_tables(ssq_cwt_plan* pl) {
   if (int rc = upload_tw<T>(&pl->d_tw1, P1, P1, 1)) return rc;
   if (int rc = upload_tw<T>(&pl->d_tw2, P2, P2, 1)) return rc;
   if (pl->two_step) {
+    // in-tile factors of the W_P twiddle (the other factor, W_P^(t0 k), is formed per tile in LDS)
+    auto upload_f2 = [&](void** dst, long long rows, long long cols, bool row_is_k) -> int {
+      std::vector<cpx<T>> h((size_t)(rows * cols));
+      for (long long i = 0; i < rows; ++i)
+        for (long long j = 0; j < cols; ++j) {
+          const long double ang = 2.0L * kPI * (long double)(i * j) / (long double)pl->P;   // c*k either way
+          h[(size_t)(i * cols + j)] = {(T)cosl(ang), (T)(-sinl(ang))};
+        }
+      (void)row_is_k;
+      SSQ_HIP(hipMalloc(dst, sizeof(cpx<T>) * h.size()));
+      SSQ_HIP(hipMemcpy(*dst, h.data(), sizeof(cpx<T>) * h.size(), hipMemcpyHostToDevice));
+      return 0;
+    };
+    if (int rc = upload_f2(&pl->d_f2a, P1, cwt_tile_rows<T>(pl->log_p1), true)) return rc;
+    for (int lq = 4; lq <= 12; ++lq) {
+      bool used = false;
+      for (int v : pl->zoom_logq) used = used || v == lq;
+      if (!used) continue;
+      if (int rc = upload_f2(&pl->d_f2z[lq], cwt_tile_rows<T>(lq), 1LL << lq, false)) return rc;
+    }
     std::vector<cpx<T>> hz(2 * kZoomMaxQ);
     for (long long Q = 16; Q <= kZoomMaxQ; Q *= 2)
       for (long long i = 0; i < Q; ++i) {
@@ -88,6 +113,8 @@ int build_tables(ssq_cwt_plan* pl) {
   SSQ_HIP(hipMalloc(&pl->d_scale_l1, sizeof(T) * (pl->na > 0 ? pl->na : 1)));
   SSQ_HIP(hipMalloc(&pl->d_scale_l2, sizeof(T) * (pl->na > 0 ? pl->na : 1)));
   SSQ_HIP(hipMalloc((void**)&pl->d_scales, sizeof(double) * (pl->na > 0 ? pl->na : 1)));
+  SSQ_HIP(hipMalloc((void**)&pl->d_band, sizeof(int) * (pl->na > 0 ? pl->na : 1)));
+  if (pl->na > 0) SSQ_HIP(hipMemcpy(pl->d_band, pl->band.data(), sizeof(int) * pl->na, hipMemcpyHostToDevice));
   if (pl->na > 0) {
     SSQ_HIP(hipMemcpy(pl->d_scale_l1, s1.data(), sizeof(T) * pl->na, hipMemcpyHostToDevice));
     SSQ_HIP(hipMemcpy(pl->d_scale_l2, s2.data(), sizeof(T) * pl->na, hipMemcpyHostToDevice));
@@ -132,6 +159,8 @@ CwtDev<T> base_dev(const ssq_cwt_plan* pl, char* ws) {
   p.psih = (const T*)pl->d_psih;
   p.tw_hi = (const cpx<T>*)pl->d_twhi;
   p.tw_lo = (const cpx<T>*)pl->d_twlo;
+  p.band = pl->d_band;
+  p.tw_f2 = (const cpx<T>*)pl->d_f2a;
   p.n_signal = pl->N;
   p.P = pl->P;
   p.n1 = pl->n1;
@@ -202,6 +231,7 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
       z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
+      z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
       SSQ_HIP(launch_cwt_tile<T>(CWT_INV_Z, z, st));
     } else {
       for (int c0 = s0; c0 < s1; c0 += pl->chunk) {
@@ -273,7 +303,6 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     q.dWx = dW;
     q.Tx = (cpx<T>*)d_Tx + b * plane;
     q.wk = d_dbg_wk ? (cpx<T>*)d_dbg_wk + b * plane : nullptr;
-    SSQ_HIP(hipMemsetAsync(q.Tx, 0, (size_t)plane * sizeof(cpx<T>), st));
     SSQ_HIP(launch_cwt_reassign<T>(q, st));
     if (d_dbg_Wx)
       SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
@@ -324,6 +353,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   } else {
     pl->two_step = true;
     pl->log_p2 = lp / 2;
+    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // experiment switch
     pl->log_p1 = lp - pl->log_p2;
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
@@ -332,6 +362,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   if (ch > (na > 0 ? na : 1)) ch = (na > 0 ? na : 1);
   pl->chunk = (int)ch;
   pl->zoom_logq.assign((size_t)na, 0);
+  pl->band.assign((size_t)na, (int)(pl->P / 2 + 1));
   if (pl->two_step) {
     const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
     const double wmax = wavelet_support(wavelet, dtype);
@@ -339,6 +370,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       const double a = scales[i];
       if (!(a > 0.0) || !std::isfinite(a)) continue;
       const double kb = wmax / (a * h) + 2.0;                        // psih_i[k] == 0 for k >= kb
+      if (kb < (double)(pl->P / 2 + 1)) pl->band[(size_t)i] = (int)kb + 1;
       if (kb > (double)kZoomMaxQ) continue;
       int lq = 4;
       while ((double)(1LL << lq) < kb) ++lq;
@@ -360,6 +392,9 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_tw1);
   hipFree(pl->d_tw2);
   hipFree(pl->d_twz);
+  hipFree(pl->d_f2a);
+  for (void* q : pl->d_f2z) hipFree(q);
+  hipFree(pl->d_band);
   hipFree(pl->d_twhi);
   hipFree(pl->d_twlo);
   hipFree(pl->d_scale_l1);

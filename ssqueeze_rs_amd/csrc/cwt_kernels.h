@@ -25,7 +25,9 @@ struct CwtDev {
   const cpx<T>* tw_m;    // W_M^i for the transform length of this launch
   const cpx<T>* tw_hi;   // W_P^(i << 12)
   const cpx<T>* tw_lo;   // W_P^i, i < 4096
+  const cpx<T>* tw_f2;   // in-tile factor of the W_P twiddle: step A [M][C]: W_P^(c k1); mode Z [C][M]: W_P^(c k)
   const T* out_scale;    // [na] 1/P (* sqrt(a) if !l1_norm)          (cwt.rs:251-262)
+  const int* band;       // [na] psih_s[k] == 0 for k >= band[s] (<= P/2 + 1)
   cpx<T>* Wx;            // [na][cols]
   cpx<T>* dWx;           // [na][cols] or NULL
   long long n_signal;
@@ -43,6 +45,9 @@ struct CwtDev {
 
 template <typename T>
 hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream);
+// transforms per tile (C) of the length-2^logm tile kernel: the host sizes the tw_f2 tables with it
+template <typename T>
+int cwt_tile_rows(int logm);
 
 // wavelet table psih[s][k] = psi_hat(scale_s * 2*pi*k/P), k in [0, P/2]   (cwt.rs:492-547)
 template <typename T>

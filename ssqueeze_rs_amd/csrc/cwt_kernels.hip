@@ -21,7 +21,12 @@
 
 namespace ssq {
 
-constexpr int kTileThreads = 512;   // 8 waves per block (one block per CU: the tile takes most of the LDS)
+// Threads per tile block: 8 waves (one block per CU: the tile takes most of the LDS).  16 waves with twiddles read
+// from the table instead of registers measured 10 % slower on C4.
+template <typename T>
+constexpr int tile_threads() {
+  return 512;
+}
 
 constexpr int pow2_floor(int v) {
   int r = 1;
@@ -33,15 +38,24 @@ template <typename T, int LOGM>
 struct TileCfg {
   static constexpr int M = 1 << LOGM;
   static constexpr int L = M / 16;                                    // lanes per transform
-  static constexpr int TPR = (L >= kTileThreads) ? 1 : kTileThreads / L;   // transforms per round
+  static constexpr int THREADS = tile_threads<T>();
+  static constexpr int TPR = (L >= THREADS) ? 1 : THREADS / L;   // transforms per round
   static constexpr int ROWP = M + M / 16 + 1;                         // odd-ish pitch: bank spread
   static constexpr int ROW_BYTES = ROWP * (int)sizeof(cpx<T>);
-  static constexpr int CCAP = (sizeof(T) == 4) ? 16 : 8;              // >= 128-B global segments
+#ifndef SSQ_CWT_CCAP32
+#define SSQ_CWT_CCAP32 16
+#endif
+  static constexpr int CCAP = (sizeof(T) == 4) ? SSQ_CWT_CCAP32 : 8;   // >= 128-B global segments
   static constexpr int CFIT = pow2_floor(160 * 1024 / ROW_BYTES);
   static constexpr int CWANT = (TPR > CCAP) ? TPR : CCAP;
   static constexpr int C = (CWANT < CFIT) ? CWANT : CFIT;             // transforms per tile
   static constexpr int LDS_BYTES = C * ROW_BYTES;
   static constexpr bool MULTIWAVE = (L > 64);
+  // W_P^(t0 k), k < M, of the tile's first column / residue t0, kept beside the tile when it fits: the W_P twiddle
+  // of element (c, k) is then f1[k] * tw_f2[c, k] -- one LDS read and one COALESCED table load instead of two
+  // 64-address gathers from the split W_P table (which made step A's store phase TA-bound)
+  static constexpr bool F1 = (LDS_BYTES + M * (int)sizeof(cpx<T>) <= 160 * 1024);
+  static constexpr int LDS_TOTAL = LDS_BYTES + (F1 ? M * (int)sizeof(cpx<T>) : 0);
   static_assert(LOGM >= 4 && LOGM <= 12, "tile FFT length");
   static_assert(C >= TPR && C % TPR == 0, "whole rounds");
 };
@@ -102,27 +116,49 @@ __device__ __forceinline__ cpx<T> twiddle_P(const CwtDev<T>& p, long long r) {
 // One tile = C transforms of length M in LDS.  MODE is a compile-time CwtMode: every phase is straight-line code
 // over batches of U elements per thread, so U global loads (or stores) are in flight per thread instead of one.
 template <typename T, int LOGM, int MODE>
-__global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
+#ifndef SSQ_CWT_MINBLK
+#define SSQ_CWT_MINBLK 1
+#endif
+__global__ __launch_bounds__(tile_threads<T>(), (sizeof(T) == 4 && TileCfg<T, LOGM>::LDS_TOTAL <= 80 * 1024) ? SSQ_CWT_MINBLK : 1) void cwt_tile_kernel(CwtDev<T> p) {
   using K = TileCfg<T, LOGM>;
   constexpr int M = K::M, L = K::L, C = K::C, ROWP = K::ROWP;
-  constexpr bool TW_REGS = (sizeof(T) == 4);
+  constexpr int kTileThreads = K::THREADS;
+  // twiddles in registers pay only when a thread runs several rounds with them
+  constexpr bool TW_REGS = (sizeof(T) == 4) && (C / K::TPR > 1);
   constexpr bool inv = MODE >= CWT_INV_A;
   constexpr bool stepA = (MODE == CWT_FWD_A || MODE == CWT_INV_A);
   constexpr bool stepB = (MODE == CWT_FWD_B || MODE == CWT_INV_B);
   constexpr bool stepZ = (MODE == CWT_INV_Z);
   static_assert((C * M) % kTileThreads == 0, "whole sweeps");
   constexpr int PER = C * M / kTileThreads;             // elements per thread and phase
-  constexpr int U = PER < 8 ? PER : 8;                  // batch
+#ifndef SSQ_CWT_U
+#define SSQ_CWT_U 8
+#endif
+  constexpr int U = PER < SSQ_CWT_U ? PER : SSQ_CWT_U;  // batch
   static_assert(PER % U == 0, "whole batches");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS_BYTES];
+  constexpr bool USE_F1 = K::F1 && (MODE == CWT_FWD_A || MODE == CWT_INV_A || MODE == CWT_INV_Z);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[USE_F1 ? K::LDS_TOTAL : K::LDS_BYTES];
   cpx<T>* rows = reinterpret_cast<cpx<T>*>(smem);
+  cpx<T>* f1 = reinterpret_cast<cpx<T>*>(smem + K::LDS_BYTES);
 
   const int tid = threadIdx.x;
   const int tr = blockIdx.y;
+#ifdef SSQ_CWT_XCD
+  // blocks go round-robin over the 8 XCDs: give each XCD a contiguous range of tiles, so that the neighbouring
+  // tiles whose sub-line segments share cache lines meet in one L2
+  const long long tile = (gridDim.x % 8 == 0) ? (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+                                              : (long long)blockIdx.x;
+#else
   const long long tile = blockIdx.x;
+#endif
   const long long P2 = 1LL << p.log_p2;
   const long long P1 = 1LL << p.log_p1;
   const long long t0 = tile * C;                        // first column (A) / row (B) / residue (Z) / transform (S)
+
+  if constexpr (USE_F1) {
+    for (int k = tid; k < M; k += kTileThreads) f1[k] = twiddle_P(p, t0 * k);   // t0 k < P
+    if constexpr (stepZ) __syncthreads();                 // Z uses it in the load phase, A only in the store phase
+  }
 
   // ---------------- load (conjugated for inverse transforms) ----------------
   // element e of the tile -> its LDS slot; A walks columns fastest (C-element global segments), the others walk
@@ -146,7 +182,10 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
       long long d = t0 + e / M;
       const bool live = d < P1;                          // D < C: partial tile
       if (!live) d = 0;
-      const cpx<T> w = twiddle_P(p, (long long)k * d);   // k d < Q D = P;  W_P^(k d) = conj(e^{+2 pi i k d/P})
+      // W_P^(k d) = conj(e^{+2 pi i k d/P}), k d < Q D = P
+      cpx<T> w;
+      if constexpr (USE_F1) w = cmul(f1[k], p.tw_f2[(e / M) * M + k]);
+      else w = twiddle_P(p, (long long)k * d);
       cpx<T> v = cmul(conj_if(load_spectrum(p, tr, k), true), w);
       if (!live) v = {(T)0, (T)0};
       return v;
@@ -158,11 +197,25 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
       else return conj_if(load_spectrum(p, (int)trc, m), true);
     }
   };
+  // step A of an inverse transform: rows at and above ceil(band / P2) of the [P1][P2] view hold only zeros
+  long long live_elems = (long long)C * M;
+  if constexpr (MODE == CWT_INV_A) {
+    const long long band = p.band[p.scale0 + tr / p.n_kinds];
+    live_elems = ((band + P2 - 1) / P2) * C;              // e = r*C + c < live_elems  <=>  r < live rows
+  }
 #pragma unroll 1
   for (int i0 = 0; i0 < PER; i0 += U) {
     cpx<T> buf[U];
+#ifndef SSQ_CWT_ABL
+#define SSQ_CWT_ABL 0
+#endif
+    if (!(SSQ_CWT_ABL & 1) && (long long)i0 * kTileThreads < live_elems) {   // uniform: whole batches of dead rows issue no loads
 #pragma unroll
-    for (int u = 0; u < U; ++u) buf[u] = fetch(tid + (i0 + u) * kTileThreads);
+      for (int u = 0; u < U; ++u) buf[u] = fetch(tid + (i0 + u) * kTileThreads);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) buf[u] = {(T)0, (T)0};
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) rows[slot_of(tid + (i0 + u) * kTileThreads)] = buf[u];
   }
@@ -190,7 +243,7 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
       }
     }
 #pragma unroll 1
-    for (int round = 0; round < C / K::TPR; ++round) {
+    for (int round = 0; round < ((SSQ_CWT_ABL & 2) ? 0 : C / K::TPR); ++round) {
       cpx<T>* row = rows + (round * K::TPR + slot) * ROWP;
       cpx<T> v[16];
 #pragma unroll
@@ -218,7 +271,10 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
       if constexpr (stepA) {
         const int c = e % C, k1 = e / C;
         const long long col = t0 + c;
-        buf[u] = cmul(rows[c * ROWP + exch_phys(k1)], twiddle_P(p, col * k1));   // col k1 < P1 P2 = P
+        cpx<T> w;                                            // W_P^(col k1), col k1 < P1 P2 = P
+        if constexpr (USE_F1) w = cmul(f1[k1], p.tw_f2[k1 * C + c]);
+        else w = twiddle_P(p, col * k1);
+        buf[u] = cmul(rows[c * ROWP + exch_phys(k1)], w);
       } else if constexpr (stepB || stepZ) {
         buf[u] = conj_if(rows[(e % C) * ROWP + exch_phys(e / C)], inv);
       } else {
@@ -228,6 +284,7 @@ __global__ __launch_bounds__(kTileThreads) void cwt_tile_kernel(CwtDev<T> p) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int e = tid + (i0 + u) * kTileThreads;
+      if ((SSQ_CWT_ABL & 4) && buf[u].x != (T)12345.678) continue;   // ablation: compute, do not write
       if constexpr (stepA) {
         const int c = e % C, k1 = e / C;
         p.ybuf[(long long)tr * p.P + (long long)k1 * P2 + t0 + c] = buf[u];
@@ -259,7 +316,7 @@ static hipError_t launch_tile_mode(const CwtDev<T>& p, hipStream_t stream) {
   } else {
     grid = dim3((unsigned)((p.n_transforms + K::C - 1) / K::C), 1, 1);
   }
-  hipLaunchKernelGGL((cwt_tile_kernel<T, LOGM, MODE>), grid, dim3(kTileThreads), 0, stream, p);
+  hipLaunchKernelGGL((cwt_tile_kernel<T, LOGM, MODE>), grid, dim3(K::THREADS), 0, stream, p);
   return hipGetLastError();
 }
 
@@ -378,82 +435,110 @@ hipError_t launch_cwt_naive_inv(const CwtDev<T>& p, int n_transforms, hipStream_
 }
 
 // ------------------------------------------------ phase transform + reassignment ----
-// ssq_cwt.rs:15-47 (phase_cwt) and :116-222 (ssqueeze).  One thread owns one time column and
-// walks the scales in ascending order -- the reference's accumulation order, no atomics.
+// ssq_cwt.rs:15-47 (phase_cwt) and :116-222 (ssqueeze).
+// Phase transform and bin of one (scale, time) element: returns the Tx row (after flipud) or -1.
+template <typename T>
+__device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cpx<T> dW, T& w) {
+  const T two_pi = (T)(2.0 * 3.14159265358979323846);
+  bool small;
+  if constexpr (sizeof(T) == 4) {
+    // pre-scaled ratio: the reference's GMW is un-normalised (peak ~4e17), so |Wx|^2 and
+    // b*c - a*d overflow fp32 long before the ratio does
+    const T mx = fmaxf(fabsf(Wv.x), fabsf(Wv.y));
+    const T sc = (T)1 / mx;
+    const T cs = Wv.x * sc, ds = Wv.y * sc;
+    const T den = Wv.x * cs + Wv.y * ds;               // |Wx|^2 / mx
+    small = !(mx * sqrtf(cs * cs + ds * ds) >= p.gamma);
+    w = fabsf((dW.y * cs - dW.x * ds) / (den * two_pi));
+  } else {
+    const T den = Wv.x * Wv.x + Wv.y * Wv.y;
+    small = hypot(Wv.x, Wv.y) < p.gamma;               // Complex::norm()  ssq_cwt.rs:29
+    w = fabs((dW.y * Wv.x - dW.x * Wv.y) / (den * two_pi));
+  }
+  if (small) w = (T)INFINITY;
+  int kk = -1;
+  if (!(isinf(w) || w != w)) {                         // ssq_cwt.rs:167
+    T v;
+    if (p.is_log) v = (log2(w) - p.bin_min) / p.bin_step;    // ssq_cwt.rs:175-176
+    else v = (w - p.bin_min) / p.bin_step;                   // ssq_cwt.rs:187
+    const T r = round(v);                              // half away from zero
+    int bin;
+    if (r != r) bin = 0;                               // NaN as isize == 0
+    else if (r < (T)0 || r >= (T)p.na) bin = -1;       // out of range: dropped (:177,:188)
+    else bin = (int)r;
+    if (bin >= 0) kk = p.flipud ? (p.na - 1 - bin) : bin;
+  }
+  return kk;
+}
+
+// One thread owns one time column and walks the scales in ascending order -- the reference's accumulation order, no
+// atomics -- read-modify-writing a zero-filled Tx.  (An LDS-resident Tx tile [na][64 columns] with the rows split
+// over 4 waves was measured 2.5x slower on C4: 128 KB of LDS leaves 4 waves per CU, too few loads in flight.)
 template <typename T>
 __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.N) return;
-  const T two_pi = (T)(2.0 * 3.14159265358979323846);
   const cpx<T>* __restrict__ Wxp = p.Wx + j;
   const cpx<T>* __restrict__ dWxp = p.dWx + j;
   constexpr int UN = 8;                                  // scales whose Wx / dWx loads are in flight together
   for (int i0 = 0; i0 < p.na; i0 += UN) {
-  cpx<T> Wb[UN], dWb[UN];
+    cpx<T> Wb[UN], dWb[UN];
 #pragma unroll
-  for (int u = 0; u < UN; ++u) {
-    const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
-    Wb[u] = Wxp[(long long)ii * p.N];
-    dWb[u] = dWxp[(long long)ii * p.N];
-  }
+    for (int u = 0; u < UN; ++u) {
+      const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
+      Wb[u] = Wxp[(long long)ii * p.N];
+      dWb[u] = dWxp[(long long)ii * p.N];
+    }
 #pragma unroll
-  for (int u = 0; u < UN; ++u) {
-    const int i = i0 + u;
-    if (i >= p.na) break;
-    const long long o = (long long)i * p.N + j;
-    const cpx<T> Wv = Wb[u], dW = dWb[u];
-    T w;
-    bool small;
-    if constexpr (sizeof(T) == 4) {
-      // pre-scaled ratio: the reference's GMW is un-normalised (peak ~4e17), so |Wx|^2 and
-      // b*c - a*d overflow fp32 long before the ratio does
-      const T mx = fmaxf(fabsf(Wv.x), fabsf(Wv.y));
-      const T sc = (T)1 / mx;
-      const T cs = Wv.x * sc, ds = Wv.y * sc;
-      const T den = Wv.x * cs + Wv.y * ds;               // |Wx|^2 / mx
-      small = !(mx * sqrtf(cs * cs + ds * ds) >= p.gamma);
-      w = fabsf((dW.y * cs - dW.x * ds) / (den * two_pi));
-    } else {
-      const T den = Wv.x * Wv.x + Wv.y * Wv.y;
-      small = hypot(Wv.x, Wv.y) < p.gamma;               // Complex::norm()  ssq_cwt.rs:29
-      w = fabs((dW.y * Wv.x - dW.x * Wv.y) / (den * two_pi));
-    }
-    if (small) w = (T)INFINITY;
-    int kk = -1;
-    if (!(isinf(w) || w != w)) {                         // ssq_cwt.rs:167
-      T v;
-      if (p.is_log) v = (log2(w) - p.bin_min) / p.bin_step;    // ssq_cwt.rs:175-176
-      else v = (w - p.bin_min) / p.bin_step;                   // ssq_cwt.rs:187
-      const T r = round(v);                              // half away from zero
-      int bin;
-      if (r != r) bin = 0;                               // NaN as isize == 0
-      else if (r < (T)0 || r >= (T)p.na) bin = -1;       // out of range: dropped (:177,:188)
-      else bin = (int)r;
-      if (bin >= 0) kk = p.flipud ? (p.na - 1 - bin) : bin;
-    }
-    if (p.wk) p.wk[o] = {w, (T)kk};
-    if (kk >= 0) {
-      const long long d = (long long)kk * p.N + j;
-      cpx<T> acc = p.Tx[d];
-      if (p.squeezing == 1) {
-        acc.x += p.leb_val;
-      } else {
-        acc.x += Wv.x;
-        acc.y += Wv.y;
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u;
+      if (i >= p.na) break;
+      const long long o = (long long)i * p.N + j;
+      const cpx<T> Wv = Wb[u];
+      T w;
+      const int kk = reassign_bin(p, Wv, dWb[u], w);
+      if (p.wk) p.wk[o] = {w, (T)kk};
+      if (kk >= 0) {
+        const long long d = (long long)kk * p.N + j;
+        cpx<T> acc = p.Tx[d];
+        if (p.squeezing == 1) {
+          acc.x += p.leb_val;
+        } else {
+          acc.x += Wv.x;
+          acc.y += Wv.y;
+        }
+        p.Tx[d] = acc;
       }
-      p.Tx[d] = acc;
     }
-  }
   }
 }
 
 template <typename T>
 hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream) {
+  const hipError_t e = hipMemsetAsync(p.Tx, 0, (size_t)p.na * (size_t)p.N * sizeof(cpx<T>), stream);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(cwt_reassign_kernel<T>, dim3((unsigned)((p.N + 63) / 64)), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 
+template <typename T>
+int cwt_tile_rows(int logm) {
+  switch (logm) {
+    case 4: return TileCfg<T, 4>::C;
+    case 5: return TileCfg<T, 5>::C;
+    case 6: return TileCfg<T, 6>::C;
+    case 7: return TileCfg<T, 7>::C;
+    case 8: return TileCfg<T, 8>::C;
+    case 9: return TileCfg<T, 9>::C;
+    case 10: return TileCfg<T, 10>::C;
+    case 11: return TileCfg<T, 11>::C;
+    case 12: return TileCfg<T, 12>::C;
+  }
+  return 0;
+}
+
 #define SSQ_INST(T)                                                                                   \
+  template int cwt_tile_rows<T>(int);                                                                 \
   template hipError_t launch_cwt_tile<T>(int, const CwtDev<T>&, hipStream_t);                         \
   template hipError_t launch_wavelet_table<T>(T*, const double*, int, long long, int, hipStream_t);   \
   template hipError_t launch_cwt_naive_fwd<T>(const CwtDev<T>&, hipStream_t);                         \
