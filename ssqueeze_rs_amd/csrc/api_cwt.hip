@@ -353,7 +353,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   } else {
     pl->two_step = true;
     pl->log_p2 = lp / 2;
-    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // experiment switch
+    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch
     pl->log_p1 = lp - pl->log_p2;
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
@@ -363,7 +363,9 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   pl->chunk = (int)ch;
   pl->zoom_logq.assign((size_t)na, 0);
   pl->band.assign((size_t)na, (int)(pl->P / 2 + 1));
-  if (pl->two_step) {
+  // SSQ_CWT_NOPRUNE=1 (tests): every scale through the plain two-step transform, no band-limit shortcuts
+  const char* noprune = std::getenv("SSQ_CWT_NOPRUNE");
+  if (pl->two_step && !(noprune && noprune[0] == '1')) {
     const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
     const double wmax = wavelet_support(wavelet, dtype);
     for (int64_t i = 0; i < na; ++i) {

@@ -201,3 +201,27 @@ def test_ssq_cwt_large_two_step(dtype, tol):
     assert (dbg["k"][both] == im["k"][both]).mean() >= (0.9999 if dtype == np.float64 else 0.99)
     d = np.abs(Tx.astype(np.complex128).sum(0) - Tx_o.sum(0))
     assert np.median(d) <= (1e-9 if dtype == np.float64 else 1e-4) * wmax
+
+
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-12), (np.float32, 2e-6)])
+def test_cwt_band_limited_paths_match_plain_two_step(wavelet, dtype, tol, monkeypatch):
+    """Band-limited scales take the single-pass path (mode Z) and step A skips dead rows; both rely on the wavelet
+    table being exactly zero beyond a bound (csrc/api_cwt.hip::wavelet_support).  SSQ_CWT_NOPRUNE=1 sends every
+    scale through the plain two-step transform: the two must agree to rounding, for scales on both sides of every
+    switch (Q = 16 ... 2048, two-step) and for both wavelets."""
+    N = 40000                                    # P = 65536 = 256 x 256
+    x = _sig(N, 11, dtype)
+    scales = 2.0 ** np.linspace(0.5, 14.5, 57)
+    Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=50.0, l1_norm=False, derivative=True)
+    monkeypatch.setenv("SSQ_CWT_NOPRUNE", "1")
+    Wx0, sc0, dWx0 = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=50.0, l1_norm=False, derivative=True)
+    assert np.array_equal(sc, sc0)
+    for a, b in ((Wx, Wx0), (dWx, dWx0)):
+        row_max = np.abs(b).max(axis=1, keepdims=True)
+        assert (np.abs(a - b) <= tol * np.maximum(row_max, np.abs(b).max() * 1e-30)).all()
+    # and against the oracle, per scale (a dropped non-zero tail would show up in the large scales' rows)
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), wavelet, scales=scales, fs=50.0, l1_norm=False, derivative=True)
+    otol = 1e-11 if dtype == np.float64 else 2e-5
+    assert np.abs(Wx - Wx_o).max() <= otol * np.abs(Wx_o).max()
+    assert np.abs(dWx - dWx_o).max() <= otol * np.abs(dWx_o).max()
