@@ -352,12 +352,14 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
     pl->log_p2 = 0;
   } else {
     pl->two_step = true;
-    pl->log_p2 = lp / 2;
-    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch
+    pl->log_p2 = (lp + 1) / 2;                                    // step A gets the shorter (single-wave) transforms
+    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 1)
     pl->log_p1 = lp - pl->log_p2;
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
-  long long ch = (128LL << 20) / (2 * pl->P * csz);
+  long long chunk_mb = 128;                                      // ybuf of a chunk stays inside the 256 MB Infinity Cache
+  if (const char* e = std::getenv("SSQ_CWT_CHUNK_MB")) chunk_mb = std::atoll(e) > 0 ? std::atoll(e) : chunk_mb;   // tuning switch
+  long long ch = (chunk_mb << 20) / (2 * pl->P * csz);
   if (ch < 1) ch = 1;
   if (ch > (na > 0 ? na : 1)) ch = (na > 0 ? na : 1);
   pl->chunk = (int)ch;
