@@ -617,11 +617,22 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 //   * twiddles come from an LDS copy of the W_1024 table, samples are prefetched one tile ahead.
 // One tile = one frame per wave, so the tile barrier comes once per frame per wave.
 // ---------------------------------------------------------------------------------------------
+#ifndef SSQ_TX_CELL64
+#define SSQ_TX_CELL64 1     // Tx tile of the 16-wave kernel as 64-bit (re, im) cells: one ds_add_u64 per bin
+#endif
+#ifndef SSQ_TX_EXPAD
+#define SSQ_TX_EXPAD 1     // exchange-row padding per 16 elements (2 = conflict-free 16-element writes: measured neutral)
+#endif
+#ifndef SSQ_TX_MERGE
+#define SSQ_TX_MERGE 1      // merge the contributions of lane pairs with equal destinations before the LDS atomic
+#endif
+
 struct Hi1024 {
   static constexpr int N = 1024, L = 64, NF = 513, F = 16, PITCH = 17, W = 16;
   static constexpr int PLANE = NF * PITCH;
   static constexpr int TILE_BYTES = (((2 * PLANE + F) * 4 + 15) / 16) * 16;
-  static constexpr int EXH_ELEMS = 512 + 32;               // half a frame, +1 per 16
+  static constexpr int EXH_PAD = SSQ_TX_EXPAD;              // pad elements per 16: 2 makes a lane's 16-element write (stride 36 dwords) conflict-free
+  static constexpr int EXH_ELEMS = 512 + 32 * EXH_PAD;      // half a frame + padding
   static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
   static constexpr int TAB_BYTES = N * 8;                   // window table; twiddle tables [16][16] + [3][256] (+pad)
   static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
@@ -659,6 +670,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
   const int t = tid & 63;          // lane = position inside the frame
   const int fl = tid >> 6;         // wave = frame inside the tile
   cpx<T>* exch = exch_all + fl * H::EXH_ELEMS;
+  auto xphys = [](int i) { return i + H::EXH_PAD * (i >> 4); };
 
   for (int i = tid; i < N; i += 1024) win_lds[i] = p.win2[i];
   if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
@@ -715,19 +727,19 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       cpx<T> lo[8];
       if (t < 32) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) exch[exch_phys(16 * t + u)] = v[u];
+        for (int u = 0; u < 16; ++u) exch[xphys(16 * t + u)] = v[u];
       }
       frame_sync<false>();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) lo[q] = exch[exch_phys(t + L * q)];
+      for (int q = 0; q < 8; ++q) lo[q] = exch[xphys(t + L * q)];
       frame_sync<false>();
       if (t >= 32) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) exch[exch_phys(16 * (t - 32) + u)] = v[u];
+        for (int u = 0; u < 16; ++u) exch[xphys(16 * (t - 32) + u)] = v[u];
       }
       frame_sync<false>();
 #pragma unroll
-      for (int q = 8; q < 16; ++q) v[q] = exch[exch_phys(t + L * (q - 8))];
+      for (int q = 8; q < 16; ++q) v[q] = exch[xphys(t + L * (q - 8))];
       frame_sync<false>();
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = lo[q];
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       cpx<T> cv[9];
       int dstb[9];
       T l1 = 0.0f;
-      const int fl4 = fl * 4;
+      constexpr int CELL = SSQ_TX_CELL64 ? 8 : 4;            // bytes per tile cell (interleaved re,im) or plane element
       const float lane_on = valid ? 1.0f : 0.0f;
       const float sfs0 = (float)t * p.sfs_step, sfs_q = (float)L * p.sfs_step;
       const int neg_last = -(p.n_freqs - 1);
@@ -795,23 +807,50 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
         cv[q] = c;
         int kneg = cvt_floor_i32(__builtin_fmaf(-w, p.inv_dw, 0.5f));
         kneg = kneg < neg_last ? neg_last : kneg;
-        dstb[q] = __mul24(kneg, -(PITCH * 4)) + fl4;
+        dstb[q] = __mul24(kneg, -(PITCH * CELL)) + fl * CELL;
         l1 += fabsf(c.x) + fabsf(c.y);
       }
       const T tot = frame_allreduce<T, L, false>(l1, t, nullptr, t) * p.dw;
       T scale, inv_scale;
       column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
       if (t == 0 && valid) col_scale[fl] = inv_scale;
-      char* pre = reinterpret_cast<char*>(tile_re);
-      char* pim = reinterpret_cast<char*>(tile_im);
+      // fixed-point contributions; scatter one 64-bit add per bin into the (re, im) cell: the cell holds the signed
+      // integer IM * 2^32 + RE (|RE| < 2^31), so a borrow of a negative RE into the high word is undone exactly at
+      // the read-out (IM = high - (RE >> 31)) whatever the order of the adds
+      char* ptile = reinterpret_cast<char*>(tile_re);
+      const bool odd_lane = (t & 1) != 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        atomicAdd(reinterpret_cast<unsigned*>(pre + dstb[q]), (unsigned)cvt_round_i32(cv[q].x * scale));
-        if (!LEB) atomicAdd(reinterpret_cast<unsigned*>(pim + dstb[q]), (unsigned)cvt_round_i32(cv[q].y * scale));
-      }
-      if (t == 0) {
-        atomicAdd(reinterpret_cast<unsigned*>(pre + dstb[8]), (unsigned)cvt_round_i32(cv[8].x * scale));
-        if (!LEB) atomicAdd(reinterpret_cast<unsigned*>(pim + dstb[8]), (unsigned)cvt_round_i32(cv[8].y * scale));
+      for (int q = 0; q < 9; ++q) {
+        int ia = cvt_round_i32(cv[q].x * scale);
+        int ib = LEB ? 0 : cvt_round_i32(cv[q].y * scale);
+        bool skip = (q == 8) && (t != 0);
+#if SSQ_TX_MERGE
+        if (q < 8) {
+          // neighbouring bins are often reassigned to the same row: lanes (2i, 2i+1) with equal destinations merge
+          // their (integer, hence order-exact) contributions into one add -- same-address LDS atomics serialise
+          const int ksw = __builtin_amdgcn_update_dpp(0, dstb[q], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+          const int sa = ia + __builtin_amdgcn_update_dpp(0, ia, 0xB1, 0xF, 0xF, true);
+          const int sb = LEB ? 0 : ib + __builtin_amdgcn_update_dpp(0, ib, 0xB1, 0xF, 0xF, true);
+          const bool same = (ksw == dstb[q]);
+          ia = same ? sa : ia;
+          ib = same ? sb : ib;
+          skip = same && odd_lane;
+        }
+#endif
+        if (!skip) {
+#if SSQ_TX_CELL64
+          if (LEB) {
+            atomicAdd(reinterpret_cast<unsigned*>(ptile + dstb[q]), (unsigned)ia);             // RE >= 0: no borrow
+          } else {
+            const unsigned hi = (unsigned)(ib + (ia >> 31));
+            atomicAdd(reinterpret_cast<unsigned long long*>(ptile + dstb[q]),
+                      ((unsigned long long)hi << 32) | (unsigned)ia);
+          }
+#else
+          atomicAdd(reinterpret_cast<unsigned*>(ptile + dstb[q]), (unsigned)ia);
+          if (!LEB) atomicAdd(reinterpret_cast<unsigned*>(ptile + H::PLANE * 4 + dstb[q]), (unsigned)ib);
+#endif
+        }
       }
     }
     __syncthreads();
@@ -825,22 +864,29 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       const long long gstep = (long long)RSTEP * p.n_frames;
       const bool fvalid = EDGE ? (frame0 + f < p.n_frames) : true;
       const T sc = col_scale[f];
+      constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
+#if SSQ_TX_CELL64
+      long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + f;
+      auto sweep = [&](int j) {
+        const long long c = tc[j * RSTEP * PITCH];
+        tc[j * RSTEP * PITCH] = 0;
+        const int ire = (int)c;
+        const int iim = (int)(c >> 32) - (ire >> 31);
+        if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
+      };
+#else
       int* tr = tile_re + k0 * PITCH + f;
       int* ti = tile_im + k0 * PITCH + f;
-      constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
-#pragma unroll
-      for (int j = 0; j < NFULL; ++j) {
+      auto sweep = [&](int j) {
         const int ire = tr[j * RSTEP * PITCH], iim = ti[j * RSTEP * PITCH];
         tr[j * RSTEP * PITCH] = 0;
         ti[j * RSTEP * PITCH] = 0;
         if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
-      }
-      if (k0 + NFULL * RSTEP < NF) {
-        const int ire = tr[NFULL * RSTEP * PITCH], iim = ti[NFULL * RSTEP * PITCH];
-        tr[NFULL * RSTEP * PITCH] = 0;
-        ti[NFULL * RSTEP * PITCH] = 0;
-        if (fvalid) og[NFULL * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
-      }
+      };
+#endif
+#pragma unroll
+      for (int j = 0; j < NFULL; ++j) sweep(j);
+      if (k0 + NFULL * RSTEP < NF) sweep(NFULL);
     }
     __syncthreads();
     if (!has_next) break;
