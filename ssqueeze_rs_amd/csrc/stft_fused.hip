@@ -700,6 +700,10 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
   load_frame(sig, tile_frame0(jt), xn);
   const cpx<T> twr_unused[3][16] = {};
 
+#ifdef SSQ_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = ssq_stamp();
+#endif
 #pragma unroll 1
   while (true) {
     const int frame0 = tile_frame0(jt);
@@ -710,6 +714,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       const cpx<T> wq = win_lds[t + L * q];
       v[q] = {xn[q] * wq.x, xn[q] * wq.y};
     }
+    SSQ_STAMP(0);
     // next tile of this block; prefetch its samples behind this frame's FFT
     long long nsig = sig;
     int njt = jt + (int)gridDim.x;
@@ -719,6 +724,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
     }
     const bool has_next = nsig < n_sig;
     if (has_next) load_frame(nsig, tile_frame0(njt), xn);
+    SSQ_STAMP(1);
 
     // ---- pass 0: radix 16 over elements t + 64q ----
     fft_compute<T, 10, 0, false, false>(v, twr_unused, tw1, t);
@@ -746,6 +752,21 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
     }
     // ---- pass 1: twiddle W_256^(k m), radix 16 ----
     fft_compute<T, 10, 1, false, false, true>(v, twr_unused, tw1, t);
+#ifdef SSQ_SENS
+    {   // resource sensitivity: p.ablate = extra VALU instructions | extra LDS reads << 16 per frame (results unused)
+      const int nv = p.ablate & 0xffff, nl = (p.ablate >> 16) & 0xffff;
+      float d0 = v[0].x, d1 = v[1].x, d2 = v[2].x, d3 = v[3].x, d4 = v[4].x, d5 = v[5].x, d6 = v[6].x, d7 = v[7].x;
+      for (int i = 0; i < nv; i += 8)
+        asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3\n"
+                     "v_fma_f32 %4, %4, %4, %4\n v_fma_f32 %5, %5, %5, %5\n v_fma_f32 %6, %6, %6, %6\n v_fma_f32 %7, %7, %7, %7"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+      for (int i = 0; i < nl; ++i) {
+        const float r = reinterpret_cast<volatile float*>(exch)[2 * xphys(t + L * (i & 7))];
+        d0 += r;
+      }
+      if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 12345.678f) v[0].x = 0.0f;
+    }
+#endif
     // ---- exchange 2: producer (row m, k), reg u = 4 uh + ul  ->  consumer (row ul, k), reg 4 m + uh ----
     {
 #pragma unroll
@@ -767,6 +788,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
     fft_compute<T, 10, 2, false, false, true>(v, twr_unused, tw2 - 256, t);   // compact index m*256 + j, m = 1..3
     // lane t now holds Z[t + 64 q]
 
+    SSQ_STAMP(2);
     // ---- partner Z[N-k] for the bins this lane owns ----
     cpx<T> zp[9];
     {
@@ -782,6 +804,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       zp[8] = v[8];
     }
 
+    SSQ_STAMP(3);
     // ---- unpack, phase transform, bin index, fixed-point scatter (same arithmetic as stft_fused_kernel) ----
     {
       cpx<T> cv[9];
@@ -810,10 +833,12 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
         dstb[q] = __mul24(kneg, -(PITCH * CELL)) + fl * CELL;
         l1 += fabsf(c.x) + fabsf(c.y);
       }
+      SSQ_STAMP(4);
       const T tot = frame_allreduce<T, L, false>(l1, t, nullptr, t) * p.dw;
       T scale, inv_scale;
       column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
       if (t == 0 && valid) col_scale[fl] = inv_scale;
+      SSQ_STAMP(5);
       // fixed-point contributions; scatter one 64-bit add per bin into the (re, im) cell: the cell holds the signed
       // integer IM * 2^32 + RE (|RE| < 2^31), so a borrow of a negative RE into the high word is undone exactly at
       // the read-out (IM = high - (RE >> 31)) whatever the order of the adds
@@ -853,9 +878,14 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
         }
       }
     }
+#ifdef SSQ_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // charge the atomics' drain to their own phase
+#endif
+    SSQ_STAMP(6);
     __syncthreads();
 
     // ---- tile read-out: thread -> (frame f, rows k0 + 64 j) ----
+    SSQ_STAMP(7);
     {
       constexpr int RSTEP = 1024 / F;                       // 64 rows per sweep
       const int f = tid % F;
@@ -888,11 +918,17 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
       for (int j = 0; j < NFULL; ++j) sweep(j);
       if (k0 + NFULL * RSTEP < NF) sweep(NFULL);
     }
+    SSQ_STAMP(8);
     __syncthreads();
+    SSQ_STAMP(9);
     if (!has_next) break;
     sig = nsig;
     jt = njt;
   }
+#ifdef SSQ_STAMPS
+  if (p.stamps && t == 0)
+    for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * 16 + fl) * 12 + i] = st_acc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ launch ----

@@ -16,7 +16,8 @@ NAMES = ["wait prefetch + window", "decode + issue loads", "FFT (3 passes, 2 LDS
 lib = _lib.load()
 B, N, n_fft, hop = 64, 1 << 20, 1024, 256
 buf = C.c_void_p()
-nwaves = 256 * 8
+W = int(os.environ.get("SSQ_STAMP_WAVES", "16"))     # waves per block of the kernel under test (16-wave kernel; 8 with SSQ_HIOCC=0)
+nwaves = 256 * W
 _lib.check(lib.ssq_dev_malloc(C.byref(buf), nwaves * 12 * 8))
 _lib.check(lib.ssq_dev_memset(buf, 0, nwaves * 12 * 8, None))
 os.environ["SSQ_STAMPS_PTR"] = str(buf.value)
@@ -36,7 +37,7 @@ _lib.check(lib.ssq_memcpy_d2h(out.ctypes.data_as(C.c_void_p), buf, out.nbytes, N
 _lib.check(lib.ssq_device_sync())
 acc = out.reshape(nwaves, 12).astype(np.float64)
 # the edge-tile launch (B*3 one-tile blocks) overwrites the first blocks' slots: keep interior-only blocks
-acc = acc[8 * (B * 3 + 8):]
+acc = acc[W * (B * 3 + 8):]
 tot = acc.sum(1).mean()
 frames_per_wave = B * (4096 - 3 * 16) / nwaves
 print(f"mean cycles per wave {tot:.0f}; per frame {tot / frames_per_wave:.0f}")
