@@ -623,21 +623,29 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_TX_EXPAD
 #define SSQ_TX_EXPAD 1     // exchange-row padding per 16 elements (2 = conflict-free 16-element writes: measured neutral)
 #endif
+#ifndef SSQ_HIOCC_DEFAULT
+#define SSQ_HIOCC_DEFAULT 1
+#endif
 #ifndef SSQ_TX_MERGE
 #define SSQ_TX_MERGE 1      // merge the contributions of lane pairs with equal destinations before the LDS atomic
 #endif
 
+// WAVES = 16: one block per CU.  WAVES = 8: two independent blocks per CU (tile of 8 frames, exchange 1 through a
+// quarter-size row in four phases), whose barriers are not coupled, so that one block's LDS-bound phases can
+// overlap the other's VALU-bound ones.
+template <int WAVES>
 struct Hi1024 {
-  static constexpr int N = 1024, L = 64, NF = 513, F = 16, PITCH = 17, W = 16;
+  static constexpr int N = 1024, L = 64, NF = 513, W = WAVES, F = WAVES, PITCH = F + 1, THREADS = WAVES * 64;
   static constexpr int PLANE = NF * PITCH;
   static constexpr int TILE_BYTES = (((2 * PLANE + F) * 4 + 15) / 16) * 16;
+  static constexpr int NPH = 32 / WAVES;                    // exchange-1 phases: 2 (half rows) or 4 (quarter rows)
   static constexpr int EXH_PAD = SSQ_TX_EXPAD;              // pad elements per 16: 2 makes a lane's 16-element write (stride 36 dwords) conflict-free
-  static constexpr int EXH_ELEMS = 512 + 32 * EXH_PAD;      // half a frame + padding
+  static constexpr int EXH_ELEMS = N / NPH + (N / NPH / 16) * EXH_PAD;
   static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
   static constexpr int TAB_BYTES = N * 8;                   // window table; twiddle tables [16][16] + [3][256] (+pad)
   static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
   static constexpr int FRAC = 30, EMIN = -90;
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  static_assert(LDS_BYTES * (16 / WAVES) <= 160 * 1024, "LDS budget");
 };
 
 // 4x4 transpose of R[0..3] across the four 16-lane rows of the wave (one dword per lane per register)
@@ -652,9 +660,10 @@ __device__ __forceinline__ void rows_transpose4(float& r0, float& r1, float& r2,
   r3 = __uint_as_float(d[1]);
 }
 
-template <bool EDGE, bool LEB>
-__global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
-  using H = Hi1024;
+template <bool EDGE, bool LEB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(StftDev<float> p) {
+  using H = Hi1024<WAVES>;
+  constexpr int THREADS = H::THREADS;
   using T = float;
   constexpr int N = H::N, L = H::L, NF = H::NF, F = H::F, PITCH = H::PITCH;
   __shared__ __attribute__((aligned(16))) unsigned char smem[H::LDS_BYTES];
@@ -672,16 +681,20 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
   cpx<T>* exch = exch_all + fl * H::EXH_ELEMS;
   auto xphys = [](int i) { return i + H::EXH_PAD * (i >> 4); };
 
-  for (int i = tid; i < N; i += 1024) win_lds[i] = p.win2[i];
+  for (int i = tid; i < N; i += THREADS) win_lds[i] = p.win2[i];
   if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
-  for (int i = tid; i < 768; i += 1024) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
-  for (int i = tid; i < 2 * H::PLANE; i += 1024) tile_re[i] = 0;
+  for (int i = tid; i < 768; i += THREADS) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
+  for (int i = tid; i < 2 * H::PLANE; i += THREADS) tile_re[i] = 0;
   __syncthreads();
-  if ((long long)blockIdx.x >= p.total_tiles) return;
+  // 8-wave variant: tiles 2i and 2i+1 hold the two 64-byte halves of the same output lines; blocks b and b + 8 run
+  // on the same XCD (round-robin dispatch), so give THEM the adjacent tiles and let the halves meet in one L2
+  unsigned bid = blockIdx.x;
+  if (WAVES == 8 && gridDim.x % 16 == 0) bid = (bid / 16) * 16 + (bid % 8) * 2 + ((bid / 8) % 2);
+  if ((long long)bid >= p.total_tiles) return;
 
   const long long n_sig = p.total_tiles / p.tiles_per_signal;
-  long long sig = (long long)(blockIdx.x / (unsigned)p.tiles_per_signal);
-  int jt = (int)(blockIdx.x % (unsigned)p.tiles_per_signal);
+  long long sig = (long long)(bid / (unsigned)p.tiles_per_signal);
+  int jt = (int)(bid % (unsigned)p.tiles_per_signal);
   auto tile_frame0 = [&](int j) { return ((j < p.ta_n) ? p.ta0 + j : p.tb0 + (j - p.ta_n)) * F; };
   auto load_frame = [&](long long sg, int frame0, T (&xv)[16]) {
     const int frame = frame0 + fl;
@@ -728,27 +741,24 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
 
     // ---- pass 0: radix 16 over elements t + 64q ----
     fft_compute<T, 10, 0, false, false>(v, twr_unused, tw1, t);
-    // ---- exchange 1 through the half-size row ----
+    // ---- exchange 1 through the 1/NPH-size row: in phase ph the lanes [64 ph / NPH, 64 (ph+1) / NPH) write their
+    //      16 values (elements 16 t + u) and every lane reads back its elements t + 64 q, q in [16 ph / NPH, ...) ----
     {
-      cpx<T> lo[8];
-      if (t < 32) {
+      constexpr int NPH = H::NPH, LPP = 64 / NPH, QPP = 16 / NPH;
+      cpx<T> nv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) exch[xphys(16 * t + u)] = v[u];
+      for (int ph = 0; ph < NPH; ++ph) {
+        if (t >= ph * LPP && t < (ph + 1) * LPP) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) exch[xphys(16 * (t - ph * LPP) + u)] = v[u];
+        }
+        frame_sync<false>();
+#pragma unroll
+        for (int q = 0; q < QPP; ++q) nv[ph * QPP + q] = exch[xphys(t + L * q)];
+        frame_sync<false>();
       }
-      frame_sync<false>();
 #pragma unroll
-      for (int q = 0; q < 8; ++q) lo[q] = exch[xphys(t + L * q)];
-      frame_sync<false>();
-      if (t >= 32) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) exch[xphys(16 * (t - 32) + u)] = v[u];
-      }
-      frame_sync<false>();
-#pragma unroll
-      for (int q = 8; q < 16; ++q) v[q] = exch[xphys(t + L * (q - 8))];
-      frame_sync<false>();
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = lo[q];
+      for (int q = 0; q < 16; ++q) v[q] = nv[q];
     }
     // ---- pass 1: twiddle W_256^(k m), radix 16 ----
     fft_compute<T, 10, 1, false, false, true>(v, twr_unused, tw1, t);
@@ -887,7 +897,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
     // ---- tile read-out: thread -> (frame f, rows k0 + 64 j) ----
     SSQ_STAMP(7);
     {
-      constexpr int RSTEP = 1024 / F;                       // 64 rows per sweep
+      constexpr int RSTEP = THREADS / F;                    // 64 rows per sweep
       const int f = tid % F;
       const int k0 = tid / F;
       cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0 + f + (long long)k0 * p.n_frames;
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(1024) void stft_tx1024_kernel(StftDev<float> p) {
   }
 #ifdef SSQ_STAMPS
   if (p.stamps && t == 0)
-    for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * 16 + fl) * 12 + i] = st_acc[i];
+    for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * H::W + fl) * 12 + i] = st_acc[i];
 #endif
 }
 
@@ -943,13 +953,24 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
   int per_cu = (160 * 1024) / C::LDS_BYTES;
   if (per_cu < 1) per_cu = 1;
   if (per_cu * C::W > 32) per_cu = 32 / C::W;
+  // which kernel: SSQ_HIOCC = 0 generic 8-wave template; 1 = stft_tx1024_kernel with 16 waves, one block per CU;
+  // 2 = the same kernel with 8 waves and two independent blocks per CU (fp32, n_fft = 1024, Tx output only)
+  int hiocc = 0;
+  if constexpr (sizeof(T) == 4 && LOGN == 10) {
+    static const int mode = []() {
+      const char* e = std::getenv("SSQ_HIOCC");
+      return e ? std::atoi(e) : SSQ_HIOCC_DEFAULT;
+    }();
+    if (p0.out_kind == 0) hiocc = mode;
+  }
+  const int TF = hiocc == 2 ? 8 : (hiocc == 1 ? 16 : C::F);   // frames per tile of the kernel that will run
   // interior tiles [lo, hi): every frame of the tile reads only inside the signal
-  const long long span = (long long)C::F * p0.hop;
-  const int tps_all = (p0.n_frames + C::F - 1) / C::F;
+  const long long span = (long long)TF * p0.hop;
+  const int tps_all = (p0.n_frames + TF - 1) / TF;
   long long lo = (p0.pad_left + span - 1) / span;
-  long long hi_num = p0.n_signal - C::N - (long long)(C::F - 1) * p0.hop + p0.pad_left;
+  long long hi_num = p0.n_signal - C::N - (long long)(TF - 1) * p0.hop + p0.pad_left;
   long long hi = hi_num >= 0 ? hi_num / span + 1 : 0;
-  const long long full = p0.n_frames / C::F;
+  const long long full = p0.n_frames / TF;
   if (hi > full) hi = full;
   if (lo > tps_all) lo = tps_all;
   if (hi < lo) hi = lo;
@@ -972,21 +993,24 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
     if (blocks > p.total_tiles) blocks = p.total_tiles;
     const dim3 g((unsigned)blocks), b(C::W * 64);
     if constexpr (sizeof(T) == 4 && LOGN == 10) {
-      static const bool hiocc = []() {
-        const char* e = std::getenv("SSQ_HIOCC");
-        return e ? std::atoi(e) != 0 : true;
-      }();
-      if (hiocc && p.out_kind == 0) {
-        long long nb = cu_count;                      // one 1024-thread block per CU
+      if (hiocc) {
+        const int per = hiocc == 2 ? 2 : 1;           // blocks per CU
+        long long nb = (long long)cu_count * per;
         if (nb > p.total_tiles) nb = p.total_tiles;
-        const dim3 gh((unsigned)nb), bh(1024);
+        const dim3 gh((unsigned)nb), bh(hiocc == 2 ? 512 : 1024);
+#define SSQ_LAUNCH_HI(E, LB)                                                                          \
+  do {                                                                                                \
+    if (hiocc == 2) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 8>), gh, bh, 0, stream, p);         \
+    else hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16>), gh, bh, 0, stream, p);                   \
+  } while (0)
         if (p.squeezing == 1) {
-          if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, true>), gh, bh, 0, stream, p);
-          else hipLaunchKernelGGL((stft_tx1024_kernel<false, true>), gh, bh, 0, stream, p);
+          if (edge) SSQ_LAUNCH_HI(true, true);
+          else SSQ_LAUNCH_HI(false, true);
         } else {
-          if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false>), gh, bh, 0, stream, p);
-          else hipLaunchKernelGGL((stft_tx1024_kernel<false, false>), gh, bh, 0, stream, p);
+          if (edge) SSQ_LAUNCH_HI(true, false);
+          else SSQ_LAUNCH_HI(false, false);
         }
+#undef SSQ_LAUNCH_HI
         const hipError_t eh = hipGetLastError();
         if (eh != hipSuccess) return eh;
         continue;
