@@ -209,7 +209,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(B, args.log2n, n_fft, hop),
-                         "kernel": "stft_tx1024_kernel<false,false> (interior tiles; the edge-tile launch of the same pass is inside the timed events)", "kernel_ms_avg": k_avg,
+                         "kernel": "stft_tx1024_kernel<false,false,16> (interior tiles; the edge-tile launch of the same pass is inside the timed events)", "kernel_ms_avg": k_avg,
                          "kernel_ms_min": float(np.min(kern_ms)),
                          "alg_bytes_per_launch": B * alg_bytes_per_signal},
             "device": name.value.decode(), "cu_count": cu.value,
