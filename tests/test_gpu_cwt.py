@@ -225,3 +225,18 @@ def test_cwt_band_limited_paths_match_plain_two_step(wavelet, dtype, tol, monkey
     otol = 1e-11 if dtype == np.float64 else 2e-5
     assert np.abs(Wx - Wx_o).max() <= otol * np.abs(Wx_o).max()
     assert np.abs(dWx - dWx_o).max() <= otol * np.abs(dWx_o).max()
+
+
+def test_cwt_c5_size_scale_subset():
+    """BASELINE config 5 geometry (N = 2^22 -> P = 2^23 = 2048 x 4096 two-step FFT, fp64) on a subset of its 256
+    log scales that spans every path (plain two-step, dead-row skipping, single-pass Q = 2048 ... 16): index
+    arithmetic at full size against the oracle."""
+    N = 1 << 22
+    x = _sig(N, 21)
+    scales = (2.0 ** np.linspace(1, 21, 256))[[0, 37, 90, 140, 171, 200, 231, 255]]
+    Wx, sc, dWx = _rs.cwt(x, wavelet="morlet", scales=scales, derivative=True)
+    Wx_o, _, dWx_o = o.cwt(x, "morlet", scales=scales, derivative=True)
+    assert Wx.shape == (8, N)
+    for i in range(8):                                    # per scale: a lost tail would hide behind the largest row
+        assert np.abs(Wx[i] - Wx_o[i]).max() <= 1e-11 * np.abs(Wx_o[i]).max(), i
+        assert np.abs(dWx[i] - dWx_o[i]).max() <= 1e-11 * np.abs(dWx_o[i]).max(), i
