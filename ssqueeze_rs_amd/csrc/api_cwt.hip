@@ -352,8 +352,8 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
     pl->log_p2 = 0;
   } else {
     pl->two_step = true;
-    pl->log_p2 = (lp + 1) / 2;                                    // step A gets the shorter (single-wave) transforms
-    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 1)
+    pl->log_p2 = lp / 2;                                          // step B gets the shorter transforms (two blocks per CU)
+    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 0)
     pl->log_p1 = lp - pl->log_p2;
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;

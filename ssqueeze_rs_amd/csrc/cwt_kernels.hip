@@ -39,7 +39,9 @@ constexpr int pow2_floor(int v) {
   return r;
 }
 
-template <typename T, int LOGM>
+// NARROW (inverse step B in fp32): 8 transforms per tile instead of 16, so that two blocks share a CU and one's load /
+// store phases overlap the other's FFT (C4: -2 % against 16-row tiles; for step A and mode Z the 16-row tile wins).
+template <typename T, int LOGM, bool NARROW = false>
 struct TileCfg {
   static constexpr int M = 1 << LOGM;
   static constexpr int L = M / 16;                                    // lanes per transform
@@ -50,7 +52,7 @@ struct TileCfg {
 #ifndef SSQ_CWT_CCAP32
 #define SSQ_CWT_CCAP32 16
 #endif
-  static constexpr int CCAP = (sizeof(T) == 4) ? SSQ_CWT_CCAP32 : 8;   // >= 128-B global segments
+  static constexpr int CCAP = (sizeof(T) == 4) ? (NARROW ? 8 : SSQ_CWT_CCAP32) : 8;   // >= 128-B (64-B) global segments
   static constexpr int CFIT = pow2_floor(160 * 1024 / ROW_BYTES);
   static constexpr int CWANT = (TPR > CCAP) ? TPR : CCAP;
   static constexpr int C = (CWANT < CFIT) ? CWANT : CFIT;             // transforms per tile
@@ -118,14 +120,17 @@ __device__ __forceinline__ cpx<T> twiddle_P(const CwtDev<T>& p, long long r) {
   return cmul(p.tw_hi[r >> 12], p.tw_lo[r & 4095]);
 }
 
+template <typename T, int MODE>
+constexpr bool tile_narrow() {
+  return sizeof(T) == 4 && MODE == CWT_INV_B;
+}
+
 // One tile = C transforms of length M in LDS.  MODE is a compile-time CwtMode: every phase is straight-line code
 // over batches of U elements per thread, so U global loads (or stores) are in flight per thread instead of one.
 template <typename T, int LOGM, int MODE>
-#ifndef SSQ_CWT_MINBLK
-#define SSQ_CWT_MINBLK 1
-#endif
-__global__ __launch_bounds__(tile_threads<T>(), (sizeof(T) == 4 && TileCfg<T, LOGM>::LDS_TOTAL <= 80 * 1024) ? SSQ_CWT_MINBLK : 1) void cwt_tile_kernel(CwtDev<T> p) {
-  using K = TileCfg<T, LOGM>;
+__global__ __launch_bounds__(tile_threads<T>(), (tile_narrow<T, MODE>() && TileCfg<T, LOGM, true>::LDS_TOTAL <= 80 * 1024) ? 2 : 1)
+void cwt_tile_kernel(CwtDev<T> p) {
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
   constexpr int M = K::M, L = K::L, C = K::C, ROWP = K::ROWP;
   constexpr int kTileThreads = K::THREADS;
   // twiddles in registers pay only when a thread runs several rounds with them
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(tile_threads<T>(), (sizeof(T) == 4 && TileCfg<T, LO
 
 template <typename T, int LOGM, int MODE>
 static hipError_t launch_tile_mode(const CwtDev<T>& p, hipStream_t stream) {
-  using K = TileCfg<T, LOGM>;
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
   dim3 grid;
   if (MODE == CWT_FWD_A || MODE == CWT_INV_A) {
     grid = dim3((unsigned)(((1LL << p.log_p2) + K::C - 1) / K::C), (unsigned)p.n_transforms, 1);
