@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--gather", action="store_true", help="also time the optional RCCL all_gather of Tx")
     args = ap.parse_args()
 
+    # Native libraries (RCCL prints a version banner on its first collective) write to file descriptor 1: park the
+    # real stdout and point fd 1 at stderr, so that the ONE JSON line is the only thing this process puts on stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,9 +168,9 @@ def main():
         _lib.check(lib.ssq_event_record(b_, stream))
     _lib.check(lib.ssq_stream_sync(stream))
     torch.cuda.synchronize()
+    t1 = time.perf_counter()            # this rank's K steps are complete; the MAX over ranks is taken below
     if use_dist:
         dist.barrier()
-    t1 = time.perf_counter()
 
     wall = t1 - t0
     kern_ms = []
@@ -218,7 +224,8 @@ def main():
             line["gather_ms_8sig_shards"] = gather_ms
         if not args.no_cpu_baseline and n_gpus == 1:
             line["cpu_baseline"] = cpu_baseline(N, n_fft, hop)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     for a, b_ in evs:
         lib.ssq_event_destroy(a)
