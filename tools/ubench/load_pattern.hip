@@ -10,6 +10,7 @@
 // mode 3: the read-out store pattern alone: per tile 513 rows x 16 frames of float2, 8-byte stores, 4 rows per wave instr
 // mode 4: mode 0 loads + mode 3 stores (the kernel's whole HBM-side traffic, no arithmetic)
 // mode 5: as 4 but 16-byte stores (two frames per lane)
+// mode 6: as 3 but tiles of 8 frames (64-byte row segments), 512 blocks = two per CU (the 8-wave variant's pattern)
 template <int MODE>
 __global__ __launch_bounds__(512) void kst(const float* __restrict__ x, float2* __restrict__ out, long long n_signal,
                                             int n_frames, long long total_tiles, int tiles_per_sig) {
@@ -46,6 +47,18 @@ __global__ __launch_bounds__(512) void kst(const float* __restrict__ x, float2* 
     }
   }
   if (acc == 123.456f) out[0].x = acc;
+}
+
+__global__ __launch_bounds__(512) void kst8(float2* __restrict__ out, int n_frames, long long total_tiles, int tiles_per_sig) {
+  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    const long long sig = tile / tiles_per_sig;
+    const int frame0 = (int)(tile % tiles_per_sig) * 8;
+    float2* og = out + sig * 513LL * n_frames + frame0;
+    for (int i = threadIdx.x; i < 513 * 8; i += 512) {
+      const int k = i / 8, f = i % 8;
+      og[(long long)k * n_frames + f] = float2{(float)tile, (float)i};
+    }
+  }
 }
 
 template <int MODE>
@@ -109,13 +122,14 @@ int main() {
            best * 1e6 / (frames / 256), frames * (mode == 2 ? 1024.0 : 4096.0) / (best * 1e-3) / 1e9);
   }
   float2* d_out; hipMalloc(&d_out, (size_t)B * 513 * 4096 * 8);
-  for (int mode = 3; mode < 6; ++mode) {
+  for (int mode = 3; mode < 7; ++mode) {
     float best = 1e9;
     for (int rep = 0; rep < 5; ++rep) {
       hipEventRecord(e0);
       if (mode == 3) hipLaunchKernelGGL(kst<3>, dim3(256), dim3(512), 0, 0, d_x, d_out, N, 4096, tiles, tps);
       if (mode == 4) hipLaunchKernelGGL(kst<4>, dim3(256), dim3(512), 0, 0, d_x, d_out, N, 4096, tiles, tps);
       if (mode == 5) hipLaunchKernelGGL(kst<5>, dim3(256), dim3(512), 0, 0, d_x, d_out, N, 4096, tiles, tps);
+      if (mode == 6) hipLaunchKernelGGL(kst8, dim3(512), dim3(512), 0, 0, d_out, 4096, 2 * tiles, 2 * tps);
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
