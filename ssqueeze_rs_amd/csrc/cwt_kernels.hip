@@ -125,10 +125,18 @@ constexpr bool tile_narrow() {
   return sizeof(T) == 4 && MODE == CWT_INV_B;
 }
 
+// Two blocks per CU (<= 128 VGPRs, <= 80 KB of LDS each) where the tile is small enough: inverse step B with narrow
+// tiles and the single-pass scales up to Q = 512 (fp32); their load / FFT / store phases then overlap across blocks.
+template <typename T, int LOGM, int MODE>
+constexpr int tile_blocks_per_cu() {
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
+  return (sizeof(T) == 4 && (MODE == CWT_INV_B || MODE == CWT_INV_Z) && K::LDS_TOTAL <= 80 * 1024 && K::C == K::TPR) ? 2 : 1;
+}
+
 // One tile = C transforms of length M in LDS.  MODE is a compile-time CwtMode: every phase is straight-line code
 // over batches of U elements per thread, so U global loads (or stores) are in flight per thread instead of one.
 template <typename T, int LOGM, int MODE>
-__global__ __launch_bounds__(tile_threads<T>(), (tile_narrow<T, MODE>() && TileCfg<T, LOGM, true>::LDS_TOTAL <= 80 * 1024) ? 2 : 1)
+__global__ __launch_bounds__((tile_threads<T>()), (tile_blocks_per_cu<T, LOGM, MODE>()))
 void cwt_tile_kernel(CwtDev<T> p) {
   using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
   constexpr int M = K::M, L = K::L, C = K::C, ROWP = K::ROWP;
