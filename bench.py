@@ -44,15 +44,15 @@ def measured_traffic(B, log2n, n_fft, hop):
 
 
 def synth_batch(n_distinct, N):
-    from oracle.ssq_oracle import synth_signal      # synthetic workload generator only
+    from ssqueeze_rs_amd.synth import synth_signal   # synthetic workload generator
     return np.stack([synth_signal(N, b, np.float32) for b in range(n_distinct)])
 
 
 def cpu_baseline(N, n_fft, hop, budget_s=20.0):
     """The oracle's C restatement of the reference CPU path (oracle/ssq_ref.c, kind "port"), timed on
     this box's host cores on a bounded sample of the same workload."""
-    from oracle import ref_c
-    from oracle.ssq_oracle import synth_signal
+    from oracle import ref_c                         # the only use of oracle/ here: the timed CPU baseline
+    from ssqueeze_rs_amd.synth import synth_signal
     win = np.hanning(n_fft)
     cores = ref_c.num_threads()
     bins = (n_fft // 2 + 1) * ((N - 1) // hop + 1)

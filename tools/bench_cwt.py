@@ -33,7 +33,8 @@ dx, dT, ws = C.c_void_p(), C.c_void_p(), C.c_void_p()
 _lib.check(lib.ssq_dev_malloc(C.byref(dx), B * N * es))
 _lib.check(lib.ssq_dev_malloc(C.byref(dT), B * na * N * 2 * es))
 _lib.check(lib.ssq_dev_malloc(C.byref(ws), wsb))
-x = np.random.default_rng(0).standard_normal(B * N).astype(np.float32 if es == 4 else np.float64)
+from ssqueeze_rs_amd.synth import synth_signal  # noqa: E402
+x = np.concatenate([synth_signal(N, b, np.float32 if es == 4 else np.float64) for b in range(B)])   # SURVEY §8d workload
 _lib.check(lib.ssq_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes, None))
 
 
