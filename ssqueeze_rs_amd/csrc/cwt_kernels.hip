@@ -24,7 +24,8 @@ namespace ssq {
 // Measured dead ends on C4 (interleaved A/B on one device, profiles/README.md): batches of 16 instead of 8 loads,
 // XCD-contiguous tile numbering, 16-row -> 8-row tiles with two blocks per CU, 1024-thread blocks, an LDS-resident
 // Tx tile for the reassignment, and a software-pipelined step B (next tile's ybuf loads in registers, pass twiddles
-// in LDS, stores behind the prefetch commit): none beat this form by more than 5 %.  The tile FFT is bound by the
+// in LDS, stores behind the prefetch commit), inverse step A at 2048 points as two 1024-point half transforms (radix-2
+// split with one live input: 5 % slower): none beat this form by more than 5 %.  The tile FFT is bound by the
 // LDS round trips of 8 waves (ablation: load 18, FFT 26, store 11, rest 11 us of a 62 us step-B launch).
 // Threads per tile block: 8 waves (one block per CU: the tile takes most of the LDS).  16 waves with twiddles read
 // from the table instead of registers measured 10 % slower on C4.
