@@ -240,3 +240,19 @@ def test_cwt_c5_size_scale_subset():
     for i in range(8):                                    # per scale: a lost tail would hide behind the largest row
         assert np.abs(Wx[i] - Wx_o[i]).max() <= 1e-11 * np.abs(Wx_o[i]).max(), i
         assert np.abs(dWx[i] - dWx_o[i]).max() <= 1e-11 * np.abs(dWx_o[i]).max(), i
+
+
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+def test_cwt_c4_size_scale_subset_f32(wavelet):
+    """BASELINE config 4 geometry (N = 2^20 -> P = 2^21 = 2048 x 1024 two-step FFT, fp32) on a subset of its 256 log
+    scales spanning the plain two-step path (2048-point multi-wave columns, 8-row step-B tiles), dead-row skipping and
+    the single-pass scales: per-scale agreement with the fp64 oracle."""
+    N = 1 << 20
+    x = _sig(N, 22, np.float32)
+    scales = (2.0 ** np.linspace(1, 19, 256))[[0, 30, 77, 120, 150, 165, 200, 255]]
+    Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, derivative=True)
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), wavelet, scales=scales, derivative=True)
+    assert Wx.dtype == np.complex64 and Wx.shape == (8, N)
+    for i in range(8):
+        assert np.abs(Wx[i] - Wx_o[i]).max() <= 2e-5 * np.abs(Wx_o[i]).max(), i
+        assert np.abs(dWx[i] - dWx_o[i]).max() <= 2e-5 * np.abs(dWx_o[i]).max(), i
