@@ -974,9 +974,19 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
   if (hi > full) hi = full;
   if (lo > tps_all) lo = tps_all;
   if (hi < lo) hi = lo;
-  for (int edge = 0; edge < 2; ++edge) {
+  // small jobs (a few waves of blocks, e.g. one to four 2^20-sample signals): ONE launch of the edge-capable kernel
+  // over all tiles beats two launches -- the second launch costs more than the validity logic of the first
+  const long long blocks_one_wave = (long long)cu_count * (hiocc == 2 ? 2 : (hiocc == 1 ? 1 : per_cu));
+  bool single_launch = (long long)tps_all * batch <= 4 * blocks_one_wave;   // measured break-even: a few waves
+  if (const char* e = std::getenv("SSQ_SINGLE_LAUNCH")) single_launch = std::atoi(e) != 0;   // tests: force either path
+  for (int edge = single_launch ? 1 : 0; edge < 2; ++edge) {
     StftDev<T> p = p0;
-    if (!edge) {
+    if (single_launch) {
+      p.ta0 = 0;
+      p.ta_n = tps_all;
+      p.tb0 = 0;
+      p.tiles_per_signal = tps_all;
+    } else if (!edge) {
       p.ta0 = (int)lo;
       p.ta_n = (int)(hi - lo);
       p.tb0 = 0;

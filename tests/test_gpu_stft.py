@@ -250,6 +250,22 @@ def test_ssq_stft_full_size_properties():
     assert np.abs(e_g - e_o).max() <= 2e-2 * e_o.max()
 
 
+def test_ssq_stft_interior_edge_split_equals_single_launch(monkeypatch):
+    """A fused pass is either one launch of the edge-capable kernel over all tiles (small jobs) or an interior launch
+    (no padding logic) plus an edge launch (large jobs: csrc/stft_fused.hip::launch_one).  Both must give the same
+    bits -- the fixed-point tile is order-exact -- for the 16-wave fp32 kernel and for the generic fused kernel."""
+    for dtype, n_fft, hop, N in ((np.float32, 1024, 256, 300000), (np.float64, 512, 128, 100000),
+                                 (np.float32, 256, 64, 70000)):
+        x = _sig(N, 31, dtype)
+        win = np.hanning(n_fft)
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SSQ_SINGLE_LAUNCH", mode)
+            Tx, f = _rs.ssq_stft(x, win, n_fft=n_fft, hop_len=hop)
+            outs.append(Tx)
+        assert np.array_equal(outs[0], outs[1]), (dtype, n_fft)
+
+
 # ------------------------------------------------------------- API parity ----
 def test_error_behaviour_matches_reference():
     x = _sig(1000, 9)
