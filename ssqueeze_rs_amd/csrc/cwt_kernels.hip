@@ -490,8 +490,9 @@ __device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cp
   return kk;
 }
 
-// One thread owns one time column and walks the scales in ascending order -- the reference's accumulation order, no
-// atomics -- read-modify-writing a zero-filled Tx.  (An LDS-resident Tx tile [na][64 columns] with the rows split
+// One thread owns one time column and walks the scales in ascending order (no atomics, deterministic),
+// read-modify-writing a zero-filled Tx; runs of scales that land in the same row are summed in registers first (the
+// reference adds them to the row one by one: same sum up to the order of two roundings).  (An LDS-resident Tx tile [na][64 columns] with the rows split
 // over 4 waves was measured 2.5x slower on C4: 128 KB of LDS leaves 4 waves per CU, too few loads in flight.)
 template <typename T>
 __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
@@ -500,6 +501,8 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
   const cpx<T>* __restrict__ Wxp = p.Wx + j;
   const cpx<T>* __restrict__ dWxp = p.dWx + j;
   constexpr int UN = 8;                                  // scales whose Wx / dWx loads are in flight together
+  int k_cur = -1;
+  cpx<T> acc = {(T)0, (T)0};
   for (int i0 = 0; i0 < p.na; i0 += UN) {
     cpx<T> Wb[UN], dWb[UN];
 #pragma unroll
@@ -517,18 +520,34 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
       T w;
       const int kk = reassign_bin(p, Wv, dWb[u], w);
       if (p.wk) p.wk[o] = {w, (T)kk};
+      // consecutive scales that land in the same row are summed in registers and written once (near a ridge many do)
+      if (kk != k_cur) {
+        if (k_cur >= 0) {
+          const long long d = (long long)k_cur * p.N + j;
+          cpx<T> t = p.Tx[d];
+          t.x += acc.x;
+          t.y += acc.y;
+          p.Tx[d] = t;
+        }
+        k_cur = kk;
+        acc = {(T)0, (T)0};
+      }
       if (kk >= 0) {
-        const long long d = (long long)kk * p.N + j;
-        cpx<T> acc = p.Tx[d];
         if (p.squeezing == 1) {
           acc.x += p.leb_val;
         } else {
           acc.x += Wv.x;
           acc.y += Wv.y;
         }
-        p.Tx[d] = acc;
       }
     }
+  }
+  if (k_cur >= 0) {
+    const long long d = (long long)k_cur * p.N + j;
+    cpx<T> t = p.Tx[d];
+    t.x += acc.x;
+    t.y += acc.y;
+    p.Tx[d] = t;
   }
 }
 
