@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: TF-bins/s of ssq_stft (n_fft=1024, hop=256, fp32) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B | --total-batch B] [--gather]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One "step" = one pass of the fused ssq_stft hot path over one batch of B synthetic signals of
-2^20 samples resident in HBM (default B = 256 per GPU: BASELINE.json's target workload
-"batch=256 x 2^20-sample signals on 1xMI355X"; with N GPUs every rank processes its own B
-signals -> weak scaling, no data-path collective).  Rank 0 prints ONE JSON line.
+One "step" = one pass of the fused ssq_stft hot path over one batch of synthetic signals of 2^20 samples resident
+in HBM.  Default: B = 256 signals per GPU (BASELINE.json's target workload "batch=256 x 2^20-sample signals on
+1xMI355X"); with N GPUs every rank processes its own B signals -> weak scaling, no data-path collective.
+`--total-batch B` instead splits ONE batch of B signals over the ranks by contiguous blocks (BASELINE config 3:
+256 signals -> 32 per GPU at N = 8) -> strong scaling.  Rank 0 prints ONE JSON line.
 
-torch is plumbing only (process group, barrier, torch.cuda.synchronize); device memory, the
+The number of GPUs is the WORLD SIZE, never the flag: under torch.distributed.run `--gpus` must equal WORLD_SIZE
+(exit 2 otherwise); started as plain `python bench.py --gpus N` with N > 1 the script launches the N rank
+processes itself (fresh children through torch.distributed.run, before this process touches any GPU) and
+relays their JSON line and exit code.
+
+Outside the timed region the bench checks what it timed: three signals of the batch are copied back and compared
+bitwise with the single-signal path of the same library, and signal 0 with the committed BASELINE-config-2
+checksums (tests/golden/c2_summary.npz) -> "validated".
+
+torch is plumbing only (process group, barrier, torch.cuda.synchronize, the buffer handed to RCCL); the
 stream, the HIP events and the kernels all come from libssq_hip.so through its C-ABI.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,14 +38,92 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="signals per GPU (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="signals in the whole job, split over the ranks (strong scaling; BASELINE config 3 = 256)")
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--n-fft", type=int, default=1024)
+    ap.add_argument("--hop", type=int, default=256)
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic signals per rank (0 = all of them distinct); fewer are tiled to the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fp64 and one-signal (C2) secondary legs")
+    ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the optional RCCL all_gather of the Tx shards")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------- launcher ----
+def world_from_env(env=None):
+    """(world, rank, local_rank) of this process; (1, 0, 0) when not started by torch.distributed.run."""
+    env = os.environ if env is None else env
+    if "RANK" in env and "WORLD_SIZE" in env:
+        return int(env["WORLD_SIZE"]), int(env["RANK"]), int(env.get("LOCAL_RANK", env["RANK"]))
+    return 1, 0, 0
+
+
+def launch_plan(gpus, env=None):
+    """What this process has to do, decided before anything touches a GPU:
+    ("run", world, rank, local_rank)  -- be a rank (world == gpus), or
+    ("spawn", gpus)                   -- plain `python bench.py --gpus N`, N > 1: start N rank processes, or
+    ("error", message)                -- --gpus disagrees with the world size the launcher gave us."""
+    env = os.environ if env is None else env
+    world, rank, local_rank = world_from_env(env)
+    in_dist = "RANK" in env and "WORLD_SIZE" in env
+    if in_dist:
+        if gpus != world:
+            return ("error", f"--gpus {gpus} disagrees with WORLD_SIZE {world}: the number of GPUs is the world size")
+        return ("run", world, rank, local_rank)
+    if gpus > 1:
+        return ("spawn", gpus)
+    if gpus < 1:
+        return ("error", "--gpus must be >= 1")
+    return ("run", 1, 0, 0)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, script=None, extra_env=None):
+    """Start n fresh rank processes through torch.distributed.run (this process has made no GPU call) and wait.
+    Their stdout (rank 0's JSON line) passes straight through; returns the launcher's exit code."""
+    script = script or os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if extra_env:
+        env.update(extra_env)
+    return subprocess.call(cmd, env=env)
+
+
+def job_shape(world, rank, batch, total_batch):
+    """(signals of this rank, first global signal index, signals of the whole job, scaling)."""
+    from ssqueeze_rs_amd.batch import shard_bounds
+    if total_batch > 0:
+        lo, hi = shard_bounds(total_batch, world, rank)
+        return hi - lo, lo, total_batch, "strong"
+    return batch, rank * batch, batch * world, "weak"
+
+
+# ------------------------------------------------------------------------------------------------- pieces ----
 def measured_traffic(B, log2n, n_fft, hop):
-    """HBM bytes per launch from the committed PMC run of this kernel (profiles/r01_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied).  Traffic is per signal, so
-    other batch sizes scale it; other shapes have no measurement -> None."""
+    """HBM bytes per launch from the committed PMC run of this kernel (separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 correction applied; see profiles/README.md).  Counters cannot be read from inside
+    the timed process, so this is a per-signal figure scaled to the batch; other shapes -> None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["log2n"], w["n_fft"], w["hop"]) != (log2n, n_fft, hop):
@@ -43,9 +133,9 @@ def measured_traffic(B, log2n, n_fft, hop):
         return None
 
 
-def synth_batch(n_distinct, N):
+def synth_rows(first, count, N, dtype):
     from ssqueeze_rs_amd.synth import synth_signal   # synthetic workload generator
-    return np.stack([synth_signal(N, b, np.float32) for b in range(n_distinct)])
+    return np.stack([synth_signal(N, first + b, dtype) for b in range(count)])
 
 
 def cpu_baseline(N, n_fft, hop, budget_s=20.0):
@@ -78,19 +168,157 @@ def cpu_baseline(N, n_fft, hop, budget_s=20.0):
     }
 
 
+class Leg:
+    """One device-resident ssq_stft workload: plan + buffers + HIP-event timing on the launch stream."""
+
+    def __init__(self, lib, _lib, dtype, N, n_fft, hop, B, stream, d_out_ptr=None):
+        self.lib, self._lib = lib, _lib
+        self.f32 = dtype == np.float32
+        self.esz = 4 if self.f32 else 8
+        self.N, self.n_fft, self.hop, self.B, self.stream = N, n_fft, hop, B, stream
+        self.n_freqs, self.n_frames = n_fft // 2 + 1, (N - 1) // hop + 1
+        self.bins = self.n_freqs * self.n_frames
+        self.alg_bytes_per_signal = self.esz * N + 2 * self.esz * self.bins     # SURVEY §8(d): x in once, Tx out once
+        win = np.hanning(n_fft)
+        self.plan = C.c_void_p()
+        _lib.check(lib.ssq_stft_plan_create(C.byref(self.plan), _lib.SSQ_F32 if self.f32 else _lib.SSQ_F64, N,
+                                            win.ctypes.data_as(C.c_void_p), n_fft, hop, 1.0, 0, 0, -1.0, 0))
+        assert lib.ssq_stft_plan_is_fused(self.plan) == 1
+        self.d_x = C.c_void_p()
+        _lib.check(lib.ssq_dev_malloc(C.byref(self.d_x), B * N * self.esz))
+        self.own_out = d_out_ptr is None
+        self.d_out = C.c_void_p()
+        if self.own_out:
+            _lib.check(lib.ssq_dev_malloc(C.byref(self.d_out), B * self.bins * 2 * self.esz))
+        else:
+            self.d_out = C.c_void_p(d_out_ptr)
+        self.d_one = C.c_void_p()
+        _lib.check(lib.ssq_dev_malloc(C.byref(self.d_one), self.bins * 2 * self.esz))
+
+    def upload(self, host):
+        """host: [nd, N] rows, tiled to the batch."""
+        nd = host.shape[0]
+        for b in range(self.B):
+            row = host[b % nd]
+            self._lib.check(self.lib.ssq_memcpy_h2d(C.c_void_p(self.d_x.value + b * self.N * self.esz),
+                                                    row.ctypes.data_as(C.c_void_p), self.N * self.esz, self.stream))
+        self._lib.check(self.lib.ssq_stream_sync(self.stream))
+
+    def step(self):
+        self._lib.check(self.lib.ssq_stft_plan_exec(self.plan, self._lib.OUT_TX, self.d_x, self.B, self.d_out,
+                                                    None, 0, self.stream))
+
+    def timed(self, steps, warmup, before=None, after=None):
+        """`steps` timed steps bracketed by `before()` / `after()` (barrier + synchronize); returns
+        (wall seconds, per-step kernel ms from HIP events recorded on the launch stream)."""
+        lib, _lib = self.lib, self._lib
+        for _ in range(warmup):
+            self.step()
+        _lib.check(lib.ssq_stream_sync(self.stream))
+        evs = []
+        for _ in range(steps):
+            a, b_ = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.ssq_event_create(C.byref(a)))
+            _lib.check(lib.ssq_event_create(C.byref(b_)))
+            evs.append((a, b_))
+        if before:
+            before()
+        t0 = time.perf_counter()
+        for a, b_ in evs:
+            _lib.check(lib.ssq_event_record(a, self.stream))
+            self.step()
+            _lib.check(lib.ssq_event_record(b_, self.stream))
+        _lib.check(lib.ssq_stream_sync(self.stream))
+        if after:
+            after()
+        wall = time.perf_counter() - t0
+        kern = []
+        for a, b_ in evs:
+            ms = C.c_float(0)
+            _lib.check(lib.ssq_event_elapsed_ms(a, b_, C.byref(ms)))
+            kern.append(ms.value)
+            lib.ssq_event_destroy(a)
+            lib.ssq_event_destroy(b_)
+        return wall, kern
+
+    def fetch(self, b):
+        """Tx of signal b of the batch as it stands in HBM."""
+        cd = np.complex64 if self.f32 else np.complex128
+        out = np.empty((self.n_freqs, self.n_frames), dtype=cd)
+        self._lib.check(self.lib.ssq_memcpy_d2h(out.ctypes.data_as(C.c_void_p),
+                                                C.c_void_p(self.d_out.value + b * self.bins * 2 * self.esz),
+                                                out.nbytes, self.stream))
+        self._lib.check(self.lib.ssq_stream_sync(self.stream))
+        return out
+
+    def single(self, b):
+        """Signal b through the single-signal path (batch = 1: one launch of the edge-capable kernel)."""
+        cd = np.complex64 if self.f32 else np.complex128
+        self._lib.check(self.lib.ssq_stft_plan_exec(self.plan, self._lib.OUT_TX,
+                                                    C.c_void_p(self.d_x.value + b * self.N * self.esz), 1,
+                                                    self.d_one, None, 0, self.stream))
+        out = np.empty((self.n_freqs, self.n_frames), dtype=cd)
+        self._lib.check(self.lib.ssq_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.d_one, out.nbytes, self.stream))
+        self._lib.check(self.lib.ssq_stream_sync(self.stream))
+        return out
+
+    def validate(self, first_seed):
+        """Outside the timed region: the batch result against the single-signal path (bitwise: the fixed-point tile
+        is order-exact) and, when signal 0 is seed 0 of the C2 shape, against the committed C2 checksums."""
+        self.step()
+        self._lib.check(self.lib.ssq_stream_sync(self.stream))
+        idx = sorted({0, self.B // 2, self.B - 1})
+        rep = {"signals_checked": idx, "bitwise_equal_single_signal_path": True}
+        t0 = None
+        for b in idx:
+            got = self.fetch(b)
+            if b == 0:
+                t0 = got
+            if not np.array_equal(got, self.single(b)):
+                rep["bitwise_equal_single_signal_path"] = False
+        ok = rep["bitwise_equal_single_signal_path"] and bool(np.isfinite(t0.view(t0.real.dtype)).all())
+        gpath = os.path.join(ROOT, "tests", "golden", "c2_summary.npz")
+        if first_seed == 0 and (self.N, self.n_fft, self.hop) == (1 << 20, 1024, 256) and os.path.exists(gpath):
+            g = np.load(gpath)
+            dw = 0.5 / (self.n_freqs - 1)
+            scale = float(g["sx_absmax"]) * dw
+            e_col = float(np.abs(t0.astype(np.complex128).sum(0) - g["col_sums"]).max() / scale)
+            e_row = float(np.abs(np.abs(t0).sum(1) - g["row_energy"]).max() / g["row_energy"].max())
+            rep["c2_colsum_relerr"] = e_col       # column sums are invariant under bin flips
+            rep["c2_row_energy_relerr"] = e_row
+            tol_col = 1e-4 if self.f32 else 1e-9
+            ok = ok and e_col <= tol_col and e_row <= 2e-2
+        rep["ok"] = bool(ok)
+        return rep
+
+    def close(self):
+        self.lib.ssq_dev_free(self.d_x)
+        if self.own_out:
+            self.lib.ssq_dev_free(self.d_out)
+        self.lib.ssq_dev_free(self.d_one)
+        self.lib.ssq_stft_plan_destroy(self.plan)
+
+
+def roofline_of(leg, kern_ms, traffic, kernel_name):
+    k_avg = float(np.mean(kern_ms))
+    alg = leg.B * leg.alg_bytes_per_signal
+    achieved = alg / (k_avg * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": TRAFFIC_FILE if traffic is not None else None,
+            "kernel": kernel_name, "kernel_ms_avg": k_avg, "kernel_ms_min": float(np.min(kern_ms)),
+            "alg_bytes_per_launch": alg}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="signals per GPU")
-    ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--n-fft", type=int, default=1024)
-    ap.add_argument("--hop", type=int, default=256)
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic signals (tiled to the batch)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time the optional RCCL all_gather of Tx")
-    args = ap.parse_args()
+    args = parse_args()
+    plan = launch_plan(args.gpus)
+    if plan[0] == "error":
+        print("bench.py: " + plan[1], file=sys.stderr)
+        sys.exit(2)
+    if plan[0] == "spawn":
+        sys.exit(spawn_ranks(plan[1], sys.argv[1:]))
+    _, world, rank, local_rank = plan
 
     # Native libraries (RCCL prints a version banner on its first collective) write to file descriptor 1: park the
     # real stdout and point fd 1 at stderr, so that the ONE JSON line is the only thing this process puts on stdout.
@@ -98,144 +326,151 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
-
     # torch first: libssq_hip.so then binds to the HIP runtime torch already loaded
     import torch
     import torch.distributed as dist
-    have_cuda = torch.cuda.is_available()
-    if not have_cuda:
+    if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
+    use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == world
 
     from ssqueeze_rs_amd import _lib
     lib = _lib.load()
     _lib.check(lib.ssq_set_device(local_rank))
 
     N = 1 << args.log2n
-    n_fft, hop, B = args.n_fft, args.hop, args.batch
-    n_freqs, n_frames = n_fft // 2 + 1, (N - 1) // hop + 1
-    bins_per_signal = n_freqs * n_frames
-    alg_bytes_per_signal = 4 * N + 8 * bins_per_signal          # x once in, Tx once out (fp32)
+    n_fft, hop = args.n_fft, args.hop
+    B, first, total, scaling = job_shape(world, rank, args.batch, args.total_batch)
+    if B <= 0:
+        raise SystemExit("bench.py: a rank got no signal (total batch smaller than the world size)")
 
-    win = np.hanning(n_fft)
-    plan = C.c_void_p()
-    _lib.check(lib.ssq_stft_plan_create(C.byref(plan), _lib.SSQ_F32, N, win.ctypes.data_as(C.c_void_p),
-                                        n_fft, hop, 1.0, 0, 0, -1.0, 0))
-    assert lib.ssq_stft_plan_is_fused(plan) == 1
     stream = C.c_void_p()
     _lib.check(lib.ssq_stream_create(C.byref(stream)))
-    d_x, d_out = C.c_void_p(), C.c_void_p()
-    _lib.check(lib.ssq_dev_malloc(C.byref(d_x), B * N * 4))
-    _lib.check(lib.ssq_dev_malloc(C.byref(d_out), B * bins_per_signal * 8))
-    nd = min(args.distinct, B)
-    host = synth_batch(nd, N)                                    # seeds 0..nd-1 (+rank offset below)
-    if rank:
-        host = np.roll(host, rank, axis=0)
-    for b in range(B):
-        _lib.check(lib.ssq_memcpy_h2d(C.c_void_p(d_x.value + b * N * 4), host[b % nd].ctypes.data_as(C.c_void_p),
-                                      N * 4, stream))
-    _lib.check(lib.ssq_stream_sync(stream))
+    bins = (n_fft // 2 + 1) * ((N - 1) // hop + 1)
+    # Tx lives in a torch allocation so that the optional gather hands RCCL the real result buffer
+    out_t = torch.empty(B * bins * 2, dtype=torch.float32, device="cuda")
+    leg = Leg(lib, _lib, np.float32, N, n_fft, hop, B, stream, d_out_ptr=out_t.data_ptr())
+    nd = B if args.distinct <= 0 else min(args.distinct, B)
+    leg.upload(synth_rows(first, nd, N, np.float32))          # global signal index = seed offset
 
-    def step():
-        _lib.check(lib.ssq_stft_plan_exec(plan, _lib.OUT_TX, d_x, B, d_out, None, 0, stream))
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    _lib.check(lib.ssq_stream_sync(stream))
-
-    evs = []
-    for _ in range(args.steps):
-        a, b_ = C.c_void_p(), C.c_void_p()
-        _lib.check(lib.ssq_event_create(C.byref(a)))
-        _lib.check(lib.ssq_event_create(C.byref(b_)))
-        evs.append((a, b_))
-
+    wall, kern_ms = leg.timed(args.steps, args.warmup, before=fence, after=torch.cuda.synchronize)
     if use_dist:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for a, b_ in evs:
-        _lib.check(lib.ssq_event_record(a, stream))
-        step()
-        _lib.check(lib.ssq_event_record(b_, stream))
-    _lib.check(lib.ssq_stream_sync(stream))
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()            # this rank's K steps are complete; the MAX over ranks is taken below
-    if use_dist:
-        dist.barrier()
-
-    wall = t1 - t0
-    kern_ms = []
-    for a, b_ in evs:
-        ms = C.c_float(0)
-        _lib.check(lib.ssq_event_elapsed_ms(a, b_, C.byref(ms)))
-        kern_ms.append(ms.value)
-    if use_dist:
         tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
-    gather_ms = None
+    validation = None
+    if not args.no_validate:
+        validation = leg.validate(first)
+        if use_dist:
+            okt = torch.tensor([1 if validation["ok"] else 0], device="cuda", dtype=torch.int32)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            validation["ok_all_ranks"] = bool(okt.item())
+
+    gather = None
     if args.gather and use_dist:
-        # optional final gather of the Tx shards over xGMI (RCCL); timed separately, never part of `value`
-        shard = torch.empty(min(B, 8) * bins_per_signal * 2, device="cuda", dtype=torch.float32)
+        # optional final gather of the Tx shards over xGMI (RCCL all_gather of the REAL result buffer; equal shard
+        # sizes are required by all_gather_into_tensor, so the strong mode gathers the common minimum per rank)
+        cnt = torch.tensor([B], device="cuda", dtype=torch.int64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MIN)
+        nshare = int(cnt.item())
+        shard = out_t[: nshare * bins * 2]
         outl = torch.empty(world * shard.numel(), device="cuda", dtype=torch.float32)
         dist.all_gather_into_tensor(outl, shard)
         torch.cuda.synchronize()
+        dist.barrier()
         g0 = time.perf_counter()
         dist.all_gather_into_tensor(outl, shard)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        g_ms = (time.perf_counter() - g0) * 1e3
+        mine = outl[rank * shard.numel(): (rank + 1) * shard.numel()]
+        seen = torch.tensor([rank], device="cuda", dtype=torch.int64)
+        ranks = [torch.zeros_like(seen) for _ in range(world)]
+        dist.all_gather(ranks, seen)
+        gather = {"ms": g_ms, "bytes_per_rank": int(shard.numel() * 4), "signals_per_rank": nshare,
+                  "own_shard_round_trip_equal": bool(torch.equal(mine, shard)),
+                  "ranks_seen_by_rccl": [int(r.item()) for r in ranks]}
+        del outl
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        value = n_gpus * B * bins_per_signal * args.steps / wall
-        k_avg = float(np.mean(kern_ms))
-        achieved = B * alg_bytes_per_signal / (k_avg * 1e-3) / 1e9
+        value = total * bins * args.steps / wall
         cu = C.c_int(0)
         name = C.create_string_buffer(128)
         lib.ssq_device_info(C.byref(cu), None, name, 128)
         line = {
             "metric": "TF-bins/sec (ssq_stft, n_fft=1024)",
-            "value": value, "unit": "TF-bins/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": f"synthetic multi-sine+chirp+noise, {nd} distinct seeds tiled to the batch",
-            "config": {"workload": f"ssq_stft batch={B}/GPU x 2^{args.log2n} samples, n_fft={n_fft} hop={hop} "
-                                   f"Hann, fs=1, reflect, sum; inputs and Tx resident in HBM",
-                       "batch_per_gpu": B, "n_signal": N, "n_fft": n_fft, "hop": hop,
-                       "n_freqs": n_freqs, "n_frames": n_frames, "parallelism": f"batch-sharded x{n_gpus}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(B, args.log2n, n_fft, hop),
-                         "kernel": "stft_tx1024_kernel<false,false,16> (interior tiles; the edge-tile launch of the same pass is inside the timed events)", "kernel_ms_avg": k_avg,
-                         "kernel_ms_min": float(np.min(kern_ms)),
-                         "alg_bytes_per_launch": B * alg_bytes_per_signal},
+            "value": value, "unit": "TF-bins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32",
+            "data": f"synthetic multi-sine+chirp+noise, seeds {first}..{first + nd - 1}"
+                    + ("" if nd == B else f" tiled to the batch of {B}"),
+            "config": {"workload": f"ssq_stft batch={B}/GPU ({total} in the job) x 2^{args.log2n} samples, n_fft={n_fft} "
+                                   f"hop={hop} Hann, fs=1, reflect, sum; inputs and Tx resident in HBM",
+                       "batch_per_gpu": B, "total_batch": total, "n_signal": N, "n_fft": n_fft, "hop": hop,
+                       "n_freqs": leg.n_freqs, "n_frames": leg.n_frames, "parallelism": f"batch-sharded x{world}"},
+            "roofline": roofline_of(leg, kern_ms, measured_traffic(B, args.log2n, n_fft, hop),
+                                    "stft_tx1024_kernel<false,false,16> (interior tiles; the edge-tile launch of the "
+                                    "same pass is inside the timed events)"),
             "device": name.value.decode(), "cu_count": cu.value,
         }
-        if gather_ms is not None:
-            line["gather_ms_8sig_shards"] = gather_ms
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if validation is not None:
+            line["validated"] = bool(validation.get("ok_all_ranks", validation["ok"]))
+            line["validation"] = validation
+        if gather is not None:
+            line["gather"] = gather
+    ok = validation is None or validation.get("ok_all_ranks", validation["ok"])
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        sec = {}
+        # (1) BASELINE config 2: ONE signal (latency-bound: one launch of the edge-capable kernel)
+        one = Leg(lib, _lib, np.float32, N, n_fft, hop, 1, stream)
+        one.upload(synth_rows(0, 1, N, np.float32))
+        _, k1 = one.timed(50, 5)
+        sec["c2_one_signal_f32"] = {"ms_per_step": float(np.mean(k1)), "value": one.bins / (float(np.mean(k1)) * 1e-3),
+                                    "unit": "TF-bins/s",
+                                    "roofline_frac": one.alg_bytes_per_signal / (float(np.mean(k1)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        one.close()
+        # (2) the reference's own arithmetic: fp64 in, complex128 out, same workload
+        del out_t
+        leg.close()
+        leg = None
+        torch.cuda.empty_cache()
+        B64 = B
+        l64 = Leg(lib, _lib, np.float64, N, n_fft, hop, B64, stream)
+        l64.upload(synth_rows(first, min(nd, 16), N, np.float64))
+        _, k64 = l64.timed(max(3, args.steps // 4), 2)
+        v64 = l64.validate(first) if not args.no_validate else None
+        r64 = roofline_of(l64, k64, None, "stft_fused_kernel<double,10,true,false,false> (+ edge-tile launch)")
+        sec["f64"] = {"dtype": "f64", "batch": B64, "ms_per_step": float(np.mean(k64)),
+                      "value": B64 * l64.bins / (float(np.mean(k64)) * 1e-3), "unit": "TF-bins/s",
+                      "roofline": r64, "validated": None if v64 is None else v64["ok"]}
+        l64.close()
+        line["secondary"] = sec
+
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(N, n_fft, hop)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
-    for a, b_ in evs:
-        lib.ssq_event_destroy(a)
-        lib.ssq_event_destroy(b_)
-    lib.ssq_dev_free(d_x)
-    lib.ssq_dev_free(d_out)
-    lib.ssq_stft_plan_destroy(plan)
+    if leg is not None:
+        leg.close()
     lib.ssq_stream_destroy(stream)
     if use_dist:
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -267,7 +267,9 @@ __device__ __forceinline__ unsigned long long ssq_stamp() {
 // TXONLY = false: SSQ_OUT_SX / DSX / WK  (stft and the test hooks)
 // EDGE = false: tiles whose frames all lie inside the signal (direct loads, every frame valid);
 // EDGE = true : the few tiles per signal that touch a boundary (padding by index mirroring).
-template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB>
+// WKDBG (test hook, SSQ_OUT_WK): the TXONLY epilogue stores ITS OWN (w, k) of every bin instead of scattering, so the
+// tests observe the bins of the very arithmetic that serves SSQ_OUT_TX (k = -1 where the bin is skipped).
+template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB, bool WKDBG = false>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
@@ -446,6 +448,8 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         // ---- unpack, phase transform, bin index: branch-free; skipped bins contribute 0 ----
         cpx<T> cv[9];
         int dstb[9];                                 // byte offset of the destination inside a plane
+        T wdbg[9];
+        int kdbg[9];
         T l1 = (T)0;
         const int fl4 = fl * (int)sizeof(T);
         if constexpr (sizeof(T) == 4) {
@@ -476,6 +480,10 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             kneg = kneg < neg_last ? neg_last : kneg;
             dstb[q] = __mul24(kneg, -(PITCH * (int)sizeof(T))) + fl4;
             l1 += fabsf(c.x) + fabsf(c.y);
+            if constexpr (WKDBG) {
+              wdbg[q] = w;
+              kdbg[q] = (m != 0.0f) ? -kneg : -1;
+            }
           }
         } else {
 #pragma unroll
@@ -494,6 +502,10 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             cv[q] = c;
             dstb[q] = (keep ? kk : 0) * (PITCH * (int)sizeof(T)) + fl4;
             l1 += fabs(c.x) + fabs(c.y);
+            if constexpr (WKDBG) {
+              wdbg[q] = w;
+              kdbg[q] = keep ? kk : -1;
+            }
           }
         }
         SSQ_STAMP(4);
@@ -506,7 +518,16 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         SSQ_STAMP(5);
         char* pre = reinterpret_cast<char*>(tile_re);
         char* pim = reinterpret_cast<char*>(tile_im);
-        if constexpr (LEB) {
+        if constexpr (WKDBG) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            if ((q < 8 || t == 0) && cur[f].valid) {
+              const int o = (t + L * q) * PITCH + fl;
+              tile_re[o] = as_int<T>(wdbg[q]);
+              tile_im[o] = as_int<T>((T)kdbg[q]);
+            }
+          }
+        } else if constexpr (LEB) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
           if (t == 0) atomicAdd(reinterpret_cast<UT*>(pre + dstb[8]), (UT)to_fixed<T>(cv[8].x * scale));
@@ -565,7 +586,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             p.out + tl.sig * (long long)NF * p.n_frames + tl.frame0 + f + (long long)k0 * p.n_frames;
         const long long gstep = (long long)RSTEP * p.n_frames;
         const bool fvalid = (tl.frame0 + f < p.n_frames) && !SSQ_ABL(32);
-        const T sc = TXONLY ? col_scale[f] : (T)1;
+        const T sc = (TXONLY && !WKDBG) ? col_scale[f] : (T)1;
         IT* tr = tile_re + k0 * PITCH + f;
         IT* ti = tile_im + k0 * PITCH + f;
         constexpr int NFULL = NF / RSTEP;              // sweeps in which every thread has a row
@@ -574,7 +595,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           tr[j * RSTEP * PITCH] = 0;
           ti[j * RSTEP * PITCH] = 0;
           cpx<T> val;
-          if constexpr (TXONLY) val = {(T)ire * sc, (T)iim * sc};
+          if constexpr (TXONLY && !WKDBG) val = {(T)ire * sc, (T)iim * sc};
           else val = {from_int<T>(ire), from_int<T>(iim)};
           if (store) og[j * gstep] = val;
         };
@@ -626,6 +647,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_HIOCC_DEFAULT
 #define SSQ_HIOCC_DEFAULT 1
 #endif
+#ifndef SSQ_FREERUN_DEFAULT
+#define SSQ_FREERUN_DEFAULT 0   // 1: stft_tx1024_kernel<.., FREE = true> (arrival counters instead of tile barriers)
+#endif
 #ifndef SSQ_TX_MERGE
 #define SSQ_TX_MERGE 1      // merge the contributions of lane pairs with equal destinations before the LDS atomic
 #endif
@@ -643,7 +667,7 @@ struct Hi1024 {
   static constexpr int EXH_ELEMS = N / NPH + (N / NPH / 16) * EXH_PAD;
   static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
   static constexpr int TAB_BYTES = N * 8;                   // window table; twiddle tables [16][16] + [3][256] (+pad)
-  static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
+  static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES + 16;   // + arrival counters (FREE)
   static constexpr int FRAC = 30, EMIN = -90;
   static_assert(LDS_BYTES * (16 / WAVES) <= 160 * 1024, "LDS budget");
 };
@@ -660,7 +684,13 @@ __device__ __forceinline__ void rows_transpose4(float& r0, float& r1, float& r2,
   r3 = __uint_as_float(d[1]);
 }
 
-template <bool EDGE, bool LEB, int WAVES>
+// FREE = true: no block barrier inside the tile loop.  The two rendezvous of a tile (all scatters done -> read-out;
+// all read-outs done -> next scatter) become monotonic arrival counters in LDS that a wave polls only where it needs
+// the other waves' work: it reads out tile i-1 in the MIDDLE of tile i's FFT and checks the read-out counter just
+// before its scatter, so the waves of a CU drift up to half a tile apart instead of marching in lock step (all
+// VALU-bound, then all LDS-bound, then all storing) and nobody idles at a barrier for the slowest wave.
+// The DS unit executes a wave's LDS operations in order, so "my scatter atomics, then my arrival add" needs no wait.
+template <bool EDGE, bool LEB, int WAVES, bool WKDBG = false, bool FREE = false>
 __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(StftDev<float> p) {
   using H = Hi1024<WAVES>;
   constexpr int THREADS = H::THREADS;
@@ -674,6 +704,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES + H::EXH_BYTES);
   cpx<T>* tw1 = win_lds + N;        // pass 1: [m = 0..15][k = 0..15]   W_256^(k m)
   cpx<T>* tw2 = tw1 + 256;          // pass 2: [m = 0..2][j = 0..255]   W_1024^(j (m+1))  (row m+1 of the compact layout)
+  unsigned* sync_cnt = reinterpret_cast<unsigned*>(smem + H::LDS_BYTES - 16);   // [0] scatter arrivals, [1] read-out arrivals
 
   const int tid = threadIdx.x;
   const int t = tid & 63;          // lane = position inside the frame
@@ -685,7 +716,23 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
   for (int i = tid; i < 768; i += THREADS) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
   for (int i = tid; i < 2 * H::PLANE; i += THREADS) tile_re[i] = 0;
+  if (tid < 4) sync_cnt[tid] = 0;
   __syncthreads();
+  // arrival counters (FREE): one add per wave; a poll is a broadcast read + scalar compare; every spin is bounded
+  auto arrive = [&](int which) {
+    asm volatile("" ::: "memory");
+    if (t == 0) __hip_atomic_fetch_add(&sync_cnt[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto wait_for = [&](int which, unsigned target) {
+    for (int spins = 0; spins < (1 << 20); ++spins) {
+      const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane(
+          (int)__hip_atomic_load(&sync_cnt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if ((int)(c - target) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
   // 8-wave variant: tiles 2i and 2i+1 hold the two 64-byte halves of the same output lines; blocks b and b + 8 run
   // on the same XCD (round-robin dispatch), so give THEM the adjacent tiles and let the halves meet in one L2
   unsigned bid = blockIdx.x;
@@ -712,6 +759,47 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   T xn[16];
   load_frame(sig, tile_frame0(jt), xn);
   const cpx<T> twr_unused[3][16] = {};
+
+  // ---- tile read-out: thread -> (frame f, rows k0 + 64 j); re-zeroes what it reads ----
+  auto read_out = [&](long long rsig, int rframe0) {
+    constexpr int RSTEP = THREADS / F;                    // 64 rows per sweep
+    const int f = tid % F;
+    const int k0 = tid / F;
+    cpx<T>* __restrict__ og = p.out + rsig * (long long)NF * p.n_frames + rframe0 + f + (long long)k0 * p.n_frames;
+    const long long gstep = (long long)RSTEP * p.n_frames;
+    const bool fvalid = EDGE ? (rframe0 + f < p.n_frames) : true;
+    const T sc = col_scale[f];
+    constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
+#if SSQ_TX_CELL64
+    long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + f;
+    auto sweep = [&](int j) {
+      const long long c = tc[j * RSTEP * PITCH];
+      tc[j * RSTEP * PITCH] = 0;
+      const int ire = (int)c;
+      if constexpr (WKDBG) {
+        if (fvalid) og[j * gstep] = cpx<T>{__int_as_float(ire), __int_as_float((int)(c >> 32))};
+        return;
+      }
+      const int iim = (int)(c >> 32) - (ire >> 31);
+      if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
+    };
+#else
+    int* tr = tile_re + k0 * PITCH + f;
+    int* ti = tile_im + k0 * PITCH + f;
+    auto sweep = [&](int j) {
+      const int ire = tr[j * RSTEP * PITCH], iim = ti[j * RSTEP * PITCH];
+      tr[j * RSTEP * PITCH] = 0;
+      ti[j * RSTEP * PITCH] = 0;
+      if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
+    };
+#endif
+#pragma unroll
+    for (int j = 0; j < NFULL; ++j) sweep(j);
+    if (k0 + NFULL * RSTEP < NF) sweep(NFULL);
+  };
+  int it = 0;                  // tiles this block has scattered
+  long long psig = sig;        // previous tile (FREE: read out inside the next tile's FFT)
+  int pframe0 = 0;
 
 #ifdef SSQ_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -777,6 +865,13 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 12345.678f) v[0].x = 0.0f;
     }
 #endif
+    if constexpr (FREE) {
+      if (it > 0) {
+        wait_for(0, (unsigned)(WAVES * it));       // every wave's scatter of the previous tile has executed
+        read_out(psig, pframe0);
+        arrive(1);
+      }
+    }
     // ---- exchange 2: producer (row m, k), reg u = 4 uh + ul  ->  consumer (row ul, k), reg 4 m + uh ----
     {
 #pragma unroll
@@ -819,6 +914,8 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     {
       cpx<T> cv[9];
       int dstb[9];
+      T wdbg[9];
+      int kdbg[9];
       T l1 = 0.0f;
       constexpr int CELL = SSQ_TX_CELL64 ? 8 : 4;            // bytes per tile cell (interleaved re,im) or plane element
       const float lane_on = valid ? 1.0f : 0.0f;
@@ -842,11 +939,18 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
         kneg = kneg < neg_last ? neg_last : kneg;
         dstb[q] = __mul24(kneg, -(PITCH * CELL)) + fl * CELL;
         l1 += fabsf(c.x) + fabsf(c.y);
+        if constexpr (WKDBG) {
+          wdbg[q] = w;
+          kdbg[q] = (m != 0.0f) ? -kneg : -1;
+        }
       }
       SSQ_STAMP(4);
       const T tot = frame_allreduce<T, L, false>(l1, t, nullptr, t) * p.dw;
       T scale, inv_scale;
       column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
+      if constexpr (FREE) {
+        if (it > 0) wait_for(1, (unsigned)(WAVES * it));   // every wave has read out (and re-zeroed) the previous tile
+      }
       if (t == 0 && valid) col_scale[fl] = inv_scale;
       SSQ_STAMP(5);
       // fixed-point contributions; scatter one 64-bit add per bin into the (re, im) cell: the cell holds the signed
@@ -854,6 +958,16 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       // the read-out (IM = high - (RE >> 31)) whatever the order of the adds
       char* ptile = reinterpret_cast<char*>(tile_re);
       const bool odd_lane = (t & 1) != 0;
+      if constexpr (WKDBG) {
+        static_assert(!WKDBG || SSQ_TX_CELL64, "the (w, k) hook uses the 64-bit cells");
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          if ((q < 8 || t == 0) && valid) {
+            const unsigned lo = (unsigned)__float_as_int(wdbg[q]), hi = (unsigned)__float_as_int((float)kdbg[q]);
+            reinterpret_cast<unsigned long long*>(ptile)[(t + L * q) * PITCH + fl] = ((unsigned long long)hi << 32) | lo;
+          }
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         int ia = cvt_round_i32(cv[q].x * scale);
@@ -887,53 +1001,32 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 #endif
         }
       }
+      }
     }
 #ifdef SSQ_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // charge the atomics' drain to their own phase
 #endif
     SSQ_STAMP(6);
-    __syncthreads();
-
-    // ---- tile read-out: thread -> (frame f, rows k0 + 64 j) ----
-    SSQ_STAMP(7);
-    {
-      constexpr int RSTEP = THREADS / F;                    // 64 rows per sweep
-      const int f = tid % F;
-      const int k0 = tid / F;
-      cpx<T>* __restrict__ og = p.out + sig * (long long)NF * p.n_frames + frame0 + f + (long long)k0 * p.n_frames;
-      const long long gstep = (long long)RSTEP * p.n_frames;
-      const bool fvalid = EDGE ? (frame0 + f < p.n_frames) : true;
-      const T sc = col_scale[f];
-      constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
-#if SSQ_TX_CELL64
-      long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + f;
-      auto sweep = [&](int j) {
-        const long long c = tc[j * RSTEP * PITCH];
-        tc[j * RSTEP * PITCH] = 0;
-        const int ire = (int)c;
-        const int iim = (int)(c >> 32) - (ire >> 31);
-        if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
-      };
-#else
-      int* tr = tile_re + k0 * PITCH + f;
-      int* ti = tile_im + k0 * PITCH + f;
-      auto sweep = [&](int j) {
-        const int ire = tr[j * RSTEP * PITCH], iim = ti[j * RSTEP * PITCH];
-        tr[j * RSTEP * PITCH] = 0;
-        ti[j * RSTEP * PITCH] = 0;
-        if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
-      };
-#endif
-#pragma unroll
-      for (int j = 0; j < NFULL; ++j) sweep(j);
-      if (k0 + NFULL * RSTEP < NF) sweep(NFULL);
+    if constexpr (FREE) {
+      arrive(0);                               // this wave's scatter of tile `it` is in the LDS queue
+    } else {
+      __syncthreads();
+      SSQ_STAMP(7);
+      read_out(sig, frame0);
+      SSQ_STAMP(8);
+      __syncthreads();
     }
-    SSQ_STAMP(8);
-    __syncthreads();
     SSQ_STAMP(9);
+    psig = sig;
+    pframe0 = frame0;
+    ++it;
     if (!has_next) break;
     sig = nsig;
     jt = njt;
+  }
+  if constexpr (FREE) {
+    wait_for(0, (unsigned)(WAVES * it));       // the last tile
+    read_out(psig, pframe0);
   }
 #ifdef SSQ_STAMPS
   if (p.stamps && t == 0)
@@ -961,7 +1054,7 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
       const char* e = std::getenv("SSQ_HIOCC");
       return e ? std::atoi(e) : SSQ_HIOCC_DEFAULT;
     }();
-    if (p0.out_kind == 0) hiocc = mode;
+    if (p0.out_kind == 0 || p0.out_kind == 3) hiocc = mode;      // SSQ_OUT_WK: the (w, k) hook of the kernel that serves Tx
   }
   const int TF = hiocc == 2 ? 8 : (hiocc == 1 ? 16 : C::F);   // frames per tile of the kernel that will run
   // interior tiles [lo, hi): every frame of the tile reads only inside the signal
@@ -1008,12 +1101,26 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
         long long nb = (long long)cu_count * per;
         if (nb > p.total_tiles) nb = p.total_tiles;
         const dim3 gh((unsigned)nb), bh(hiocc == 2 ? 512 : 1024);
-#define SSQ_LAUNCH_HI(E, LB)                                                                          \
-  do {                                                                                                \
-    if (hiocc == 2) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 8>), gh, bh, 0, stream, p);         \
-    else hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16>), gh, bh, 0, stream, p);                   \
+        const char* fe = std::getenv("SSQ_FREERUN");        // read per launch: tests and A/B runs switch it in-process
+        const bool fr = (fe ? std::atoi(fe) : SSQ_FREERUN_DEFAULT) != 0 && hiocc == 1;
+#define SSQ_LAUNCH_HI(E, LB)                                                                            \
+  do {                                                                                                  \
+    if (hiocc == 2) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 8>), gh, bh, 0, stream, p);           \
+    else if (fr) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16, false, true>), gh, bh, 0, stream, p); \
+    else hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16>), gh, bh, 0, stream, p);                     \
   } while (0)
-        if (p.squeezing == 1) {
+        if (p.out_kind == 3) {
+          if (hiocc == 2) {
+            if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 8, true>), gh, bh, 0, stream, p);
+            else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 8, true>), gh, bh, 0, stream, p);
+          } else if (fr) {
+            if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 16, true, true>), gh, bh, 0, stream, p);
+            else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 16, true, true>), gh, bh, 0, stream, p);
+          } else {
+            if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 16, true>), gh, bh, 0, stream, p);
+            else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 16, true>), gh, bh, 0, stream, p);
+          }
+        } else if (p.squeezing == 1) {
           if (edge) SSQ_LAUNCH_HI(true, true);
           else SSQ_LAUNCH_HI(false, true);
         } else {
@@ -1032,6 +1139,10 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
     } else if (p.out_kind == 0) {
       if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, false>), g, b, 0, stream, p);
       else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false, false>), g, b, 0, stream, p);
+    } else if (p.out_kind == 3) {
+      // (w, k) test hook: the Tx epilogue's own bins
+      if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, false, true>), g, b, 0, stream, p);
+      else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, false, false, true>), g, b, 0, stream, p);
     } else {
       if (edge) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, true, false>), g, b, 0, stream, p);
       else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, false, false>), g, b, 0, stream, p);

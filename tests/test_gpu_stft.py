@@ -163,11 +163,10 @@ def _check_ssq_f32(x32, win, n_fft, hop, fs, pad="reflect", squeezing="sum"):
     # (c) the scatter: re-accumulate from the kernel's own Sx and k
     Tx_re = o.accumulate_tx(Sg, np.where(keep_g, dbg["k"], 0), keep_g, float(np.float32(im["dw"])),
                             Tx.shape[0], lebesgue=(squeezing == "lebesgue"))
-    # (the hook outputs come from the kernel's non-TX instantiation: a bin within an ulp of a tie may
-    # round the other way there, so allow isolated neighbour swaps but not a changed column sum)
+    # (w, k) come from the WKDBG instantiation of the very kernel that serves Tx (csrc/stft_fused.hip), so the
+    # check is strict: every element, no allowance for neighbour swaps
     tmax = np.abs(Tx_re).max()
-    assert (np.abs(Tx - Tx_re) > 2e-5 * tmax).mean() <= 5e-4
-    assert np.abs(Tx.astype(np.complex128).sum(0) - Tx_re.sum(0)).max() <= 2e-5 * tmax
+    assert np.abs(Tx - Tx_re).max() <= 2e-5 * tmax
     # (d) end-to-end against the fp64 oracle: per-column energy moves at most between neighbours
     keep_o = ~np.isinf(im["w"])
     both = keep_o & keep_g & (np.abs(im["Sx"]) > 1e-3 * smax)
