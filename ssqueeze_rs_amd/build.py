@@ -74,5 +74,10 @@ def build_lib(force: bool = False, verbose: bool = True, extra_flags=(), suffix:
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         print(build_lib(extra_flags=("-DSSQ_STAMPS", "-DSSQ_ABLATE_HOOKS"), suffix="diag"))
+    elif "--abl" in sys.argv:       # timing experiments: SSQ_ABLATE=<mask> skips stages (results wrong)
+        print(build_lib(extra_flags=("-DSSQ_ABLATE_HOOKS",), suffix="abl"))
+    elif "--variant" in sys.argv:   # python -m ssqueeze_rs_amd.build --variant NAME -DFOO=1 ...  -> libssq_hip_NAME.so
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build_lib(extra_flags=tuple(a for a in sys.argv if a.startswith("-D")), suffix=name))
     else:
         print(build_lib(force="--force" in sys.argv))

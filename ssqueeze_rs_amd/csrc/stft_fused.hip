@@ -647,11 +647,20 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_HIOCC_DEFAULT
 #define SSQ_HIOCC_DEFAULT 1
 #endif
-#ifndef SSQ_FREERUN_DEFAULT
-#define SSQ_FREERUN_DEFAULT 0   // 1: stft_tx1024_kernel<.., FREE = true> (arrival counters instead of tile barriers)
+#ifndef SSQ_XHALF
+#define SSQ_XHALF 1                // 1: exchange 1 of the 16-wave kernel by register halves (full-width LDS stores)
+#endif
+#ifndef SSQ_DPP_FUSE
+#define SSQ_DPP_FUSE 0             // 1: lane-pair merge sums as v_add_u32_dpp (inline asm) instead of v_mov_dpp + v_add
+#endif
+#ifndef SSQ_T0_ROTATE
+#define SSQ_T0_ROTATE 1            // 1: lane 0's self-partner bins by a masked register rotation instead of selects
+#endif
+#ifndef SSQ_RO_PAIR
+#define SSQ_RO_PAIR 1              // 1: read-out of the interior 16-wave kernel with 16-byte stores (two frames per thread)
 #endif
 #ifndef SSQ_TX_MERGE
-#define SSQ_TX_MERGE 1      // merge the contributions of lane pairs with equal destinations before the LDS atomic
+#define SSQ_TX_MERGE 0      // (measured: a net loss since the read-out/exchange rework, profiles/r02_ab_libs2.txt) merge the contributions of lane pairs with equal destinations before the LDS atomic
 #endif
 
 // WAVES = 16: one block per CU.  WAVES = 8: two independent blocks per CU (tile of 8 frames, exchange 1 through a
@@ -664,10 +673,11 @@ struct Hi1024 {
   static constexpr int TILE_BYTES = (((2 * PLANE + F) * 4 + 15) / 16) * 16;
   static constexpr int NPH = 32 / WAVES;                    // exchange-1 phases: 2 (half rows) or 4 (quarter rows)
   static constexpr int EXH_PAD = SSQ_TX_EXPAD;              // pad elements per 16: 2 makes a lane's 16-element write (stride 36 dwords) conflict-free
-  static constexpr int EXH_ELEMS = N / NPH + (N / NPH / 16) * EXH_PAD;
+  // the register-half exchange (WAVES = 16) lays a half row out as 64 writers x (8 values + 1 pad)
+  static constexpr int EXH_ELEMS = (WAVES == 16) ? 64 * 9 : N / NPH + (N / NPH / 16) * EXH_PAD;
   static constexpr int EXH_BYTES = W * EXH_ELEMS * 8;
   static constexpr int TAB_BYTES = N * 8;                   // window table; twiddle tables [16][16] + [3][256] (+pad)
-  static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES + 16;   // + arrival counters (FREE)
+  static constexpr int LDS_BYTES = TILE_BYTES + EXH_BYTES + 2 * TAB_BYTES;
   static constexpr int FRAC = 30, EMIN = -90;
   static_assert(LDS_BYTES * (16 / WAVES) <= 160 * 1024, "LDS budget");
 };
@@ -684,13 +694,9 @@ __device__ __forceinline__ void rows_transpose4(float& r0, float& r1, float& r2,
   r3 = __uint_as_float(d[1]);
 }
 
-// FREE = true: no block barrier inside the tile loop.  The two rendezvous of a tile (all scatters done -> read-out;
-// all read-outs done -> next scatter) become monotonic arrival counters in LDS that a wave polls only where it needs
-// the other waves' work: it reads out tile i-1 in the MIDDLE of tile i's FFT and checks the read-out counter just
-// before its scatter, so the waves of a CU drift up to half a tile apart instead of marching in lock step (all
-// VALU-bound, then all LDS-bound, then all storing) and nobody idles at a barrier for the slowest wave.
-// The DS unit executes a wave's LDS operations in order, so "my scatter atomics, then my arrival add" needs no wait.
-template <bool EDGE, bool LEB, int WAVES, bool WKDBG = false, bool FREE = false>
+// (Measured and removed in round 2: replacing the two tile barriers by arrival counters in LDS, with the read-out of
+// tile i-1 placed inside tile i's FFT or at the loop top, ran 10-14 % SLOWER -- profiles/r02_ab_freerun.txt.)
+template <bool EDGE, bool LEB, int WAVES, bool WKDBG = false>
 __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(StftDev<float> p) {
   using H = Hi1024<WAVES>;
   constexpr int THREADS = H::THREADS;
@@ -704,7 +710,6 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   cpx<T>* win_lds = reinterpret_cast<cpx<T>*>(smem + H::TILE_BYTES + H::EXH_BYTES);
   cpx<T>* tw1 = win_lds + N;        // pass 1: [m = 0..15][k = 0..15]   W_256^(k m)
   cpx<T>* tw2 = tw1 + 256;          // pass 2: [m = 0..2][j = 0..255]   W_1024^(j (m+1))  (row m+1 of the compact layout)
-  unsigned* sync_cnt = reinterpret_cast<unsigned*>(smem + H::LDS_BYTES - 16);   // [0] scatter arrivals, [1] read-out arrivals
 
   const int tid = threadIdx.x;
   const int t = tid & 63;          // lane = position inside the frame
@@ -716,23 +721,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
   for (int i = tid; i < 768; i += THREADS) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
   for (int i = tid; i < 2 * H::PLANE; i += THREADS) tile_re[i] = 0;
-  if (tid < 4) sync_cnt[tid] = 0;
   __syncthreads();
-  // arrival counters (FREE): one add per wave; a poll is a broadcast read + scalar compare; every spin is bounded
-  auto arrive = [&](int which) {
-    asm volatile("" ::: "memory");
-    if (t == 0) __hip_atomic_fetch_add(&sync_cnt[which], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-  };
-  auto wait_for = [&](int which, unsigned target) {
-    for (int spins = 0; spins < (1 << 20); ++spins) {
-      const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane(
-          (int)__hip_atomic_load(&sync_cnt[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      if ((int)(c - target) >= 0) break;
-      __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-  };
   // 8-wave variant: tiles 2i and 2i+1 hold the two 64-byte halves of the same output lines; blocks b and b + 8 run
   // on the same XCD (round-robin dispatch), so give THEM the adjacent tiles and let the halves meet in one L2
   unsigned bid = blockIdx.x;
@@ -762,12 +751,42 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 
   // ---- tile read-out: thread -> (frame f, rows k0 + 64 j); re-zeroes what it reads ----
   auto read_out = [&](long long rsig, int rframe0) {
+    if (SSQ_ABL(8)) return;
+#if SSQ_RO_PAIR && SSQ_TX_CELL64
+    if constexpr (!EDGE && !WKDBG && WAVES == 16) {
+      // thread -> (frame pair fp, rows k0 + 128 j): two adjacent cells per thread, ONE 16-byte store per row
+      // (half as many store instructions; T21 of the programming guide).  Needs even n_frames for the alignment.
+      if ((p.n_frames & 1) == 0) {
+        constexpr int RS2 = THREADS / (F / 2);              // 128 rows per sweep
+        const int fp = tid % (F / 2);
+        const int k0 = tid / (F / 2);
+        float4* __restrict__ og4 = reinterpret_cast<float4*>(p.out + rsig * (long long)NF * p.n_frames + rframe0 + 2 * fp +
+                                                             (long long)k0 * p.n_frames);
+        const long long gstep4 = (long long)RS2 * p.n_frames / 2;     // in float4 units
+        const T sc0 = col_scale[2 * fp], sc1 = col_scale[2 * fp + 1];
+        long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + 2 * fp;
+        auto sweep2 = [&](int j) {
+          const long long c0 = tc[j * RS2 * PITCH], c1 = tc[j * RS2 * PITCH + 1];
+          tc[j * RS2 * PITCH] = 0;
+          tc[j * RS2 * PITCH + 1] = 0;
+          const int r0 = (int)c0, r1 = (int)c1;
+          const int i0 = (int)(c0 >> 32) - (r0 >> 31), i1 = (int)(c1 >> 32) - (r1 >> 31);
+          if (!SSQ_ABL(4)) og4[j * gstep4] = make_float4((T)r0 * sc0, (T)i0 * sc0, (T)r1 * sc1, (T)i1 * sc1);
+        };
+        constexpr int NFULL2 = NF / RS2;                      // 4 full sweeps
+#pragma unroll
+        for (int j = 0; j < NFULL2; ++j) sweep2(j);
+        if (k0 + NFULL2 * RS2 < NF) sweep2(NFULL2);
+        return;
+      }
+    }
+#endif
     constexpr int RSTEP = THREADS / F;                    // 64 rows per sweep
     const int f = tid % F;
     const int k0 = tid / F;
     cpx<T>* __restrict__ og = p.out + rsig * (long long)NF * p.n_frames + rframe0 + f + (long long)k0 * p.n_frames;
     const long long gstep = (long long)RSTEP * p.n_frames;
-    const bool fvalid = EDGE ? (rframe0 + f < p.n_frames) : true;
+    const bool fvalid = (EDGE ? (rframe0 + f < p.n_frames) : true) && !SSQ_ABL(4);
     const T sc = col_scale[f];
     constexpr int NFULL = NF / RSTEP;                     // 8 full sweeps
 #if SSQ_TX_CELL64
@@ -797,9 +816,6 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     for (int j = 0; j < NFULL; ++j) sweep(j);
     if (k0 + NFULL * RSTEP < NF) sweep(NFULL);
   };
-  int it = 0;                  // tiles this block has scattered
-  long long psig = sig;        // previous tile (FREE: read out inside the next tile's FFT)
-  int pframe0 = 0;
 
 #ifdef SSQ_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -824,14 +840,35 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       ++nsig;
     }
     const bool has_next = nsig < n_sig;
-    if (has_next) load_frame(nsig, tile_frame0(njt), xn);
+    if (has_next && !SSQ_ABL(32)) load_frame(nsig, tile_frame0(njt), xn);
     SSQ_STAMP(1);
 
     // ---- pass 0: radix 16 over elements t + 64q ----
     fft_compute<T, 10, 0, false, false>(v, twr_unused, tw1, t);
     // ---- exchange 1 through the 1/NPH-size row: in phase ph the lanes [64 ph / NPH, 64 (ph+1) / NPH) write their
     //      16 values (elements 16 t + u) and every lane reads back its elements t + 64 q, q in [16 ph / NPH, ...) ----
-    {
+    if (WAVES == 16 && SSQ_XHALF) {
+      // exchange 1 by REGISTER halves: in phase ph EVERY lane writes its values u = 8 ph .. 8 ph + 7 (elements
+      // 16 t + u) -- full-width stores, half as many store instructions as the lane-half scheme -- and the lanes whose
+      // element residue (t & 15) lies in that half read all 16 of their elements t + 64 q = 16 ((t >> 4) + 4 q) + (t & 15).
+      // Row layout: writer lane t' at 9 t' + (u & 7): pitch 9 elements = 18 dwords keeps both the 16-lane store groups
+      // and the 32-lane load groups on distinct banks.
+      cpx<T> nv[16];
+      const int rbase = 9 * (t >> 4) + (t & 7);
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) exch[9 * t + u] = v[8 * ph + u];
+        frame_sync<false>();
+        if (((t >> 3) & 1) == ph) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) nv[q] = exch[rbase + 36 * q];
+        }
+        frame_sync<false>();
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = nv[q];
+    } else if (!SSQ_ABL(1)) {
       constexpr int NPH = H::NPH, LPP = 64 / NPH, QPP = 16 / NPH;
       cpx<T> nv[16];
 #pragma unroll
@@ -865,13 +902,6 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       if (d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 == 12345.678f) v[0].x = 0.0f;
     }
 #endif
-    if constexpr (FREE) {
-      if (it > 0) {
-        wait_for(0, (unsigned)(WAVES * it));       // every wave's scatter of the previous tile has executed
-        read_out(psig, pframe0);
-        arrive(1);
-      }
-    }
     // ---- exchange 2: producer (row m, k), reg u = 4 uh + ul  ->  consumer (row ul, k), reg 4 m + uh ----
     {
 #pragma unroll
@@ -898,15 +928,36 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     cpx<T> zp[9];
     {
       const int src = (L - t) & (L - 1);
+#if SSQ_T0_ROTATE
+      // lane 0 pairs with ITSELF one register up (N - 64 q = 64 (16 - q)): rotate its upper registers once (16 moves
+      // under a one-lane mask) instead of 16 selects; nobody else reads lane 0's upper half (src == 0 only for t == 0)
+      zp[8] = v[8];
+      if (t == 0) {
+#pragma unroll
+        for (int j = 8; j < 15; ++j) v[j] = v[j + 1];
+        v[15] = v[0];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        zp[q].x = __shfl(v[15 - q].x, src);
+        zp[q].y = __shfl(v[15 - q].y, src);
+      }
+      v[8] = zp[8];
+#else
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         cpx<T> r;
-        r.x = __shfl(v[15 - q].x, src);
-        r.y = __shfl(v[15 - q].y, src);
+        if (SSQ_ABL(16)) {
+          r = v[15 - q];
+        } else {
+          r.x = __shfl(v[15 - q].x, src);
+          r.y = __shfl(v[15 - q].y, src);
+        }
         if (t == 0) r = (q == 0) ? v[0] : v[16 - q];
         zp[q] = r;
       }
       zp[8] = v[8];
+#endif
     }
 
     SSQ_STAMP(3);
@@ -948,9 +999,6 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       const T tot = frame_allreduce<T, L, false>(l1, t, nullptr, t) * p.dw;
       T scale, inv_scale;
       column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
-      if constexpr (FREE) {
-        if (it > 0) wait_for(1, (unsigned)(WAVES * it));   // every wave has read out (and re-zeroed) the previous tile
-      }
       if (t == 0 && valid) col_scale[fl] = inv_scale;
       SSQ_STAMP(5);
       // fixed-point contributions; scatter one 64-bit add per bin into the (re, im) cell: the cell holds the signed
@@ -978,14 +1026,24 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
           // neighbouring bins are often reassigned to the same row: lanes (2i, 2i+1) with equal destinations merge
           // their (integer, hence order-exact) contributions into one add -- same-address LDS atomics serialise
           const int ksw = __builtin_amdgcn_update_dpp(0, dstb[q], 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+#if SSQ_DPP_FUSE
+          int sa, sb = 0;                          // own + neighbour in ONE instruction (the DPP operand rides on the add)
+          asm("v_add_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(sa) : "v"(ia));
+          if (!LEB) asm("v_add_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(sb) : "v"(ib));
+#else
           const int sa = ia + __builtin_amdgcn_update_dpp(0, ia, 0xB1, 0xF, 0xF, true);
           const int sb = LEB ? 0 : ib + __builtin_amdgcn_update_dpp(0, ib, 0xB1, 0xF, 0xF, true);
+#endif
           const bool same = (ksw == dstb[q]);
           ia = same ? sa : ia;
           ib = same ? sb : ib;
           skip = same && odd_lane;
         }
 #endif
+        if (SSQ_ABL(2)) {
+          asm volatile("" ::"v"(ia), "v"(ib), "v"(dstb[q]));
+          skip = true;
+        }
         if (!skip) {
 #if SSQ_TX_CELL64
           if (LEB) {
@@ -1007,26 +1065,15 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // charge the atomics' drain to their own phase
 #endif
     SSQ_STAMP(6);
-    if constexpr (FREE) {
-      arrive(0);                               // this wave's scatter of tile `it` is in the LDS queue
-    } else {
-      __syncthreads();
-      SSQ_STAMP(7);
-      read_out(sig, frame0);
-      SSQ_STAMP(8);
-      __syncthreads();
-    }
+    __syncthreads();
+    SSQ_STAMP(7);
+    read_out(sig, frame0);
+    SSQ_STAMP(8);
+    __syncthreads();
     SSQ_STAMP(9);
-    psig = sig;
-    pframe0 = frame0;
-    ++it;
     if (!has_next) break;
     sig = nsig;
     jt = njt;
-  }
-  if constexpr (FREE) {
-    wait_for(0, (unsigned)(WAVES * it));       // the last tile
-    read_out(psig, pframe0);
   }
 #ifdef SSQ_STAMPS
   if (p.stamps && t == 0)
@@ -1101,21 +1148,15 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
         long long nb = (long long)cu_count * per;
         if (nb > p.total_tiles) nb = p.total_tiles;
         const dim3 gh((unsigned)nb), bh(hiocc == 2 ? 512 : 1024);
-        const char* fe = std::getenv("SSQ_FREERUN");        // read per launch: tests and A/B runs switch it in-process
-        const bool fr = (fe ? std::atoi(fe) : SSQ_FREERUN_DEFAULT) != 0 && hiocc == 1;
 #define SSQ_LAUNCH_HI(E, LB)                                                                            \
   do {                                                                                                  \
     if (hiocc == 2) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 8>), gh, bh, 0, stream, p);           \
-    else if (fr) hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16, false, true>), gh, bh, 0, stream, p); \
     else hipLaunchKernelGGL((stft_tx1024_kernel<E, LB, 16>), gh, bh, 0, stream, p);                     \
   } while (0)
         if (p.out_kind == 3) {
           if (hiocc == 2) {
             if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 8, true>), gh, bh, 0, stream, p);
             else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 8, true>), gh, bh, 0, stream, p);
-          } else if (fr) {
-            if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 16, true, true>), gh, bh, 0, stream, p);
-            else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 16, true, true>), gh, bh, 0, stream, p);
           } else {
             if (edge) hipLaunchKernelGGL((stft_tx1024_kernel<true, false, 16, true>), gh, bh, 0, stream, p);
             else hipLaunchKernelGGL((stft_tx1024_kernel<false, false, 16, true>), gh, bh, 0, stream, p);

@@ -8,6 +8,7 @@ stream, `steps` launches each); prints per-variant median / min of the per-step 
 the 8 TB/s roof.  Also checks that every variant produces the same bits as the first one (signal 0 and the last).
 """
 import argparse
+import zlib
 import ctypes as C
 import json
 import os
@@ -78,6 +79,7 @@ def fetch(b):
 
 
 times = {v: [] for v in a.variants}
+crc = {}
 ref = None
 same = {}
 for v in a.variants:                      # warm-up + bit comparison
@@ -86,6 +88,7 @@ for v in a.variants:                      # warm-up + bit comparison
     run()
     _lib.check(lib.ssq_stream_sync(stream))
     got = (fetch(0), fetch(B - 1))
+    crc[v] = "%08x" % (zlib.crc32(got[0].tobytes()) ^ zlib.crc32(got[1].tobytes()))
     if ref is None:
         ref = got
     same[v] = bool(np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]))
@@ -109,4 +112,4 @@ for v in a.variants:
     t = np.array(times[v])
     print(json.dumps({"variant": v, "ms_median": round(float(np.median(t)), 4), "ms_min": round(float(t.min()), 4),
                       "frac_median": round(alg / (float(np.median(t)) * 1e-3) / 8e12, 4),
-                      "same_bits_as_first": same[v], "ms_all": [round(float(z), 4) for z in t]}))
+                      "same_bits_as_first": same[v], "crc": crc[v], "ms_all": [round(float(z), 4) for z in t]}))
