@@ -116,6 +116,28 @@ int64_t ssq_stft_plan_workspace_bytes(const ssq_stft_plan* plan, int64_t batch, 
 int ssq_stft_plan_exec(ssq_stft_plan* plan, int out_kind, const void* d_x, int64_t batch,
                        void* d_out, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* The same over a STRIDED batch of n_groups * group signals: signal s starts at
+ * d_x + (s / group) * group_stride + (s % group) * sig_stride (elements); windows may overlap.
+ * This is how the chunked-overlap front end (tests/stft_ssq_test.py:216-281: map_overlap with depth = n_fft) runs
+ * all extended chunks of all channels as one batch: group = chunks per channel, sig_stride = chunk,
+ * group_stride = channel pitch.  d_out: [n_groups * group][n_freqs][n_frames]. */
+int ssq_stft_plan_exec_strided(ssq_stft_plan* plan, int out_kind, const void* d_x, int64_t n_groups,
+                               int64_t group, int64_t group_stride, int64_t sig_stride, void* d_out,
+                               void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- chunked-overlap multi-channel front end (device side) ------------------
+ * Replaces the Dask harness around `_rs.*`: tests/stft_ssq_test.py:163-283, tests/ssq_cwt_test.py:66-195. */
+/* d_xext: [channels][depth + samples + depth]; the middle already holds the channel.  Fills the two array-end
+ * halos like dask.map_overlap(boundary="reflect") (mirror INCLUDING the edge sample; boundary = 1: zeros). */
+int ssq_chunk_halo_fill(int dtype, void* d_xext, int64_t channels, int64_t samples, int64_t depth,
+                        int boundary, void* stream);
+/* (channels, chunks, rows, cols) -> (rows, all chunks' columns, channels), the reference's np.transpose(stacked,
+ * (1, 2, 0)) plus the concatenation of the chunk outputs (stft_ssq_test.py:265-267), complex elements of `dtype`:
+ * out[(r*out_cols + out_col_base + j*ncols + c)*out_channels + ch_base + ch] = in[((ch*chunks + j)*rows + r)*cols_in + col0 + c] */
+int ssq_chunks_relayout(int dtype, const void* d_in, int64_t channels, int64_t chunks, int64_t rows,
+                        int64_t cols_in, int64_t col0, int64_t ncols, void* d_out, int64_t out_cols,
+                        int64_t out_col_base, int64_t out_channels, int64_t ch_base, void* stream);
+
 typedef struct ssq_cwt_plan ssq_cwt_plan;
 int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet,
                         const double* scales, int64_t na, double dt, int padtype);

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "ssq_stft_plan_is_fused": (C.c_int, [vp]),
     "ssq_stft_plan_workspace_bytes": (i64, [vp, i64, C.c_int]),
     "ssq_stft_plan_exec": (C.c_int, [vp, C.c_int, vp, i64, vp, vp, i64, vp]),
+    "ssq_stft_plan_exec_strided": (C.c_int, [vp, C.c_int, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "ssq_chunk_halo_fill": (C.c_int, [C.c_int, vp, i64, i64, i64, C.c_int, vp]),
+    "ssq_chunks_relayout": (C.c_int, [C.c_int, vp, i64, i64, i64, i64, i64, i64, vp, i64, i64, i64, i64, vp]),
     "ssq_cwt_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, i64, C.c_int, vp, i64, C.c_double, C.c_int]),
     "ssq_cwt_plan_destroy": (C.c_int, [vp]),
     "ssq_cwt_plan_workspace_bytes": (i64, [vp, i64]),

@@ -68,10 +68,18 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
   return 0;
 }
 
+struct SigLayout {
+  long long group = 1, group_stride = 0, sig_stride = 0;     // group_stride = 0: plain batch (n_signal apart)
+};
+
 template <typename T>
-StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void* d_out, long long batch) {
+StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void* d_out, long long batch,
+                    const SigLayout& lay) {
   StftDev<T> p;
   p.x = (const T*)d_x;
+  p.group = (int)lay.group;
+  p.group_stride = lay.group_stride > 0 ? lay.group_stride : pl->n_signal;
+  p.sig_stride = lay.sig_stride;
   p.out = (cpx<T>*)d_out;
   p.tw = (const cpx<T>*)pl->d_tw;
   p.win2 = (const cpx<T>*)pl->d_win2;
@@ -126,8 +134,8 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
 
 template <typename T>
 int exec_typed(ssq_stft_plan* pl, int out_kind, const void* d_x, long long batch, void* d_out,
-               void* d_ws, long long ws_bytes, hipStream_t stream) {
-  StftDev<T> p = make_dev<T>(pl, out_kind, d_x, d_out, batch);
+               void* d_ws, long long ws_bytes, hipStream_t stream, const SigLayout& lay) {
+  StftDev<T> p = make_dev<T>(pl, out_kind, d_x, d_out, batch, lay);
   if (pl->fused) {
     SSQ_HIP(launch_stft_fused<T>(p, pl->n_fft, pl->cu_count, batch, stream));
     return 0;
@@ -138,16 +146,13 @@ int exec_typed(ssq_stft_plan* pl, int out_kind, const void* d_x, long long batch
   GenericTabs tabs{pl->d_g, pl->d_gd, pl->d_twre, pl->d_twim};
   cpx<T>* ws = (cpx<T>*)d_ws;
   if (out_kind == SSQ_OUT_SX) {
-    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
-                                 pl->padtype, pl->n_frames, tabs, (cpx<T>*)d_out, nullptr, stream));
+    SSQ_HIP(launch_dft_frames<T>(p, batch, pl->n_fft, tabs, (cpx<T>*)d_out, nullptr, stream));
   } else if (out_kind == SSQ_OUT_DSX) {
-    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
-                                 pl->padtype, pl->n_frames, tabs, ws, (cpx<T>*)d_out, stream));
+    SSQ_HIP(launch_dft_frames<T>(p, batch, pl->n_fft, tabs, ws, (cpx<T>*)d_out, stream));
   } else {
     cpx<T>* Sx = ws;
     cpx<T>* dSx = ws + bins;
-    SSQ_HIP(launch_dft_frames<T>((const T*)d_x, batch, pl->n_signal, pl->n_fft, pl->hop, pl->pad_left,
-                                 pl->padtype, pl->n_frames, tabs, Sx, dSx, stream));
+    SSQ_HIP(launch_dft_frames<T>(p, batch, pl->n_fft, tabs, Sx, dSx, stream));
     SSQ_HIP(hipMemsetAsync(d_out, 0, (size_t)bins * sizeof(cpx<T>), stream));
     SSQ_HIP(launch_reassign_cols<T>(p, Sx, dSx, batch, stream));
   }
@@ -245,17 +250,35 @@ int64_t ssq_stft_plan_workspace_bytes(const ssq_stft_plan* pl, int64_t batch, in
   return 2 * bins * elem;
 }
 
-int ssq_stft_plan_exec(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t batch, void* d_out,
-                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+static int exec_any(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t batch, void* d_out,
+                    void* d_workspace, int64_t workspace_bytes, void* stream, const SigLayout& lay) {
   if (!pl) SSQ_FAIL("plan is NULL");
   if (batch <= 0) return 0;
+  if (batch > 0x7fffffff) SSQ_FAIL("batch too large");
   if (!d_x || !d_out) SSQ_FAIL("device pointer is NULL");
   if (out_kind < SSQ_OUT_TX || out_kind > SSQ_OUT_WK) SSQ_FAIL("bad out_kind");
   if ((out_kind == SSQ_OUT_TX || out_kind == SSQ_OUT_WK) && pl->n_freqs < 2)
     SSQ_FAIL("index out of bounds: ssq_freqs[1] with fewer than 2 bins (ssq_stft.rs:273)");
   if (pl->dtype == SSQ_F32)
-    return exec_typed<float>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
-  return exec_typed<double>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream);
+    return exec_typed<float>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, lay);
+  return exec_typed<double>(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, (hipStream_t)stream, lay);
+}
+
+int ssq_stft_plan_exec(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t batch, void* d_out,
+                       void* d_workspace, int64_t workspace_bytes, void* stream) {
+  return exec_any(pl, out_kind, d_x, batch, d_out, d_workspace, workspace_bytes, stream, SigLayout{});
+}
+
+int ssq_stft_plan_exec_strided(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t n_groups, int64_t group,
+                               int64_t group_stride, int64_t sig_stride, void* d_out, void* d_workspace,
+                               int64_t workspace_bytes, void* stream) {
+  if (n_groups <= 0 || group <= 0) return 0;
+  if (group_stride <= 0 || sig_stride < 0) SSQ_FAIL("bad strides");
+  SigLayout lay;
+  lay.group = group;
+  lay.group_stride = group_stride;
+  lay.sig_stride = sig_stride;
+  return exec_any(pl, out_kind, d_x, n_groups * group, d_out, d_workspace, workspace_bytes, stream, lay);
 }
 
 // Shared body of the two host entry points: upload x, run the requested outputs, download.

@@ -209,7 +209,7 @@ __device__ __forceinline__ FrameItem<T> make_frame(const StftDev<T>& p, const Ti
   w.fl = it * C::FIF + slot;
   const int frame = tl.frame0 + w.fl;
   w.valid = EDGE ? ((frame < p.n_frames) ? 1 : 0) : 1;
-  w.xs = p.x + tl.sig * p.n_signal;
+  w.xs = sig_base(p, tl.sig);
   w.pos0 = (long long)frame * p.hop - p.pad_left + t;
   return w;
 }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   auto tile_frame0 = [&](int j) { return ((j < p.ta_n) ? p.ta0 + j : p.tb0 + (j - p.ta_n)) * F; };
   auto load_frame = [&](long long sg, int frame0, T (&xv)[16]) {
     const int frame = frame0 + fl;
-    const T* xs = p.x + sg * p.n_signal;
+    const T* xs = sig_base(p, sg);
     const long long pos0 = (long long)frame * p.hop - p.pad_left + t;
     if constexpr (!EDGE) {
 #pragma unroll

@@ -13,14 +13,15 @@
 namespace ssq {
 
 template <typename T>
-__global__ void dft_frames_kernel(const T* __restrict__ x, long long n_signal, int n_fft, int hop,
-                                  int pad_left, int padtype, int n_frames, int n_freqs,
-                                  GenericTabs tabs, cpx<T>* __restrict__ Sx, cpx<T>* __restrict__ dSx) {
+__global__ void dft_frames_kernel(StftDev<T> p, int n_fft, GenericTabs tabs, cpx<T>* __restrict__ Sx,
+                                  cpx<T>* __restrict__ dSx) {
+  const long long n_signal = p.n_signal;
+  const int hop = p.hop, pad_left = p.pad_left, padtype = p.padtype, n_frames = p.n_frames, n_freqs = p.n_freqs;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;   // frame
   const int k = blockIdx.y * blockDim.y + threadIdx.y;   // bin
   const long long b = blockIdx.z;
   if (j >= n_frames || k >= n_freqs) return;
-  const T* xs = x + b * n_signal;
+  const T* xs = sig_base(p, b);
   const long long pos0 = (long long)j * hop - pad_left;
   double sr = 0, si = 0, dr = 0, di = 0;
   int idx = 0;                                            // (n*k) mod n_fft
@@ -73,14 +74,11 @@ __global__ void reassign_cols_kernel(StftDev<T> p, const cpx<T>* __restrict__ Sx
 }
 
 template <typename T>
-hipError_t launch_dft_frames(const T* x, long long batch, long long n_signal, int n_fft, int hop,
-                             int pad_left, int padtype, int n_frames, const GenericTabs& tabs,
+hipError_t launch_dft_frames(const StftDev<T>& p, long long batch, int n_fft, const GenericTabs& tabs,
                              cpx<T>* Sx, cpx<T>* dSx, hipStream_t stream) {
-  const int n_freqs = n_fft / 2 + 1;
   dim3 block(64, 4, 1);
-  dim3 grid((n_frames + 63) / 64, (n_freqs + 3) / 4, (unsigned)batch);
-  hipLaunchKernelGGL(dft_frames_kernel<T>, grid, block, 0, stream, x, n_signal, n_fft, hop, pad_left,
-                     padtype, n_frames, n_freqs, tabs, Sx, dSx);
+  dim3 grid((p.n_frames + 63) / 64, (p.n_freqs + 3) / 4, (unsigned)batch);
+  hipLaunchKernelGGL(dft_frames_kernel<T>, grid, block, 0, stream, p, n_fft, tabs, Sx, dSx);
   return hipGetLastError();
 }
 
@@ -93,10 +91,10 @@ hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx
   return hipGetLastError();
 }
 
-template hipError_t launch_dft_frames<float>(const float*, long long, long long, int, int, int, int, int,
-                                             const GenericTabs&, cpx<float>*, cpx<float>*, hipStream_t);
-template hipError_t launch_dft_frames<double>(const double*, long long, long long, int, int, int, int, int,
-                                              const GenericTabs&, cpx<double>*, cpx<double>*, hipStream_t);
+template hipError_t launch_dft_frames<float>(const StftDev<float>&, long long, int, const GenericTabs&, cpx<float>*,
+                                             cpx<float>*, hipStream_t);
+template hipError_t launch_dft_frames<double>(const StftDev<double>&, long long, int, const GenericTabs&, cpx<double>*,
+                                              cpx<double>*, hipStream_t);
 template hipError_t launch_reassign_cols<float>(const StftDev<float>&, const cpx<float>*, const cpx<float>*,
                                                 long long, hipStream_t);
 template hipError_t launch_reassign_cols<double>(const StftDev<double>&, const cpx<double>*,

@@ -12,7 +12,12 @@ struct StftDev {
   const cpx<T>* tw;        // W_N^i = exp(-2*pi*i*i/N), i in [0, N)
   const cpx<T>* win2;      // fused kernel: (g[n]/2, g'[n]*fs*alpha/2), alpha = power of two balancing the channels
   const T* ssq_freqs;      // [n_freqs] reference expression (ssq_stft.rs:50), exact fix-up table
-  long long n_signal;
+  long long n_signal;      // length of one (virtual) signal
+  // where signal `sig` of the batch starts: x + (sig / group) * group_stride + (sig % group) * sig_stride.
+  // Plain batches: group = 1, group_stride = n_signal.  The chunked front end (ssq_stft_plan_exec_strided) makes the
+  // overlapping extended chunks of one channel a group: sig_stride = chunk, group_stride = channel pitch.
+  long long sig_stride, group_stride;
+  int group;
   long long total_tiles;
   int n_frames;
   int n_freqs;
@@ -37,6 +42,13 @@ struct StftDev {
   T leb_unit;              // 1/n_freqs weight of "lebesgue" (ssq_stft.rs:294), without the dw factor
 };
 
+template <typename T>
+__device__ __forceinline__ const T* sig_base(const StftDev<T>& p, long long sig) {
+  if (p.group <= 1) return p.x + sig * p.group_stride;
+  const unsigned g = (unsigned)sig / (unsigned)p.group;
+  return p.x + (long long)g * p.group_stride + (long long)((unsigned)sig - g * (unsigned)p.group) * p.sig_stride;
+}
+
 // fused LDS-tile kernel (stft_fused.hip): 64 <= n_fft <= 4096, power of two
 template <typename T>
 bool fused_supported(int n_fft);
@@ -54,8 +66,7 @@ struct GenericTabs {
   const double* tw_im;   // [n_fft] -sin(2*pi*i/n)
 };
 template <typename T>
-hipError_t launch_dft_frames(const T* x, long long batch, long long n_signal, int n_fft, int hop,
-                             int pad_left, int padtype, int n_frames, const GenericTabs& tabs,
+hipError_t launch_dft_frames(const StftDev<T>& p, long long batch, int n_fft, const GenericTabs& tabs,
                              cpx<T>* Sx, cpx<T>* dSx /*nullable*/, hipStream_t stream);
 // Sx,dSx -> out (Tx or WK), thread per time column, rows ascending (reference order, no atomics)
 template <typename T>
