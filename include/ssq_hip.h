@@ -100,6 +100,23 @@ int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
                      void* Tx, double* ssq_freqs,
                      void* dbg_Wx, void* dbg_dWx, void* dbg_wk);
 
+/* _rs.icwt            rust/src/spectral/cwt.rs:550-718   (implemented there, advertised by _rs.pyi:61-73, not registered)
+ * Wx: [na][n_times] interleaved complex of `dtype`; scales: [n_scales_given >= na] (NULL -> "Scales must be
+ * provided"); x_len < 0 selects n_times; x_out: [x_len] float64.  one_int: scaled row sum of Re Wx (:588-627);
+ * otherwise the FFT filter bank of :629-714 for ANY x_len. */
+int ssq_icwt_host(int dtype, const void* Wx, int64_t na, int64_t n_times, int wavelet, const double* scales,
+                  int64_t n_scales_given, int one_int, int64_t x_len, double x_mean, int l1_norm, double* x_out);
+
+/* wavelet helper functions (host side, fp64): rust/src/wavelets/morlet.rs:59-145, gmw.rs:236-357, _rs.pyi:89-132.
+ * out: [n] interleaved complex128.  norm: "bandpass" (any case) or anything else = the L2 branch. */
+int ssq_morlet(const double* w, int64_t n, double mu, double* out);
+int ssq_morlet_freq(int64_t n, double scale, double mu, double* out);
+int ssq_morlet_time(int64_t n, double scale, double mu, double* out);
+int ssq_gmw(const double* w, int64_t n, double gamma, double beta, const char* norm, int order, double* out);
+int ssq_gmw_freq(int64_t n, double scale, double gamma, double beta, const char* norm, int order, double* out);
+int ssq_gmw_time(int64_t n, double scale, double gamma, double beta, const char* norm, int order, double* out);
+int ssq_gmw_center_frequency(double gamma, double beta, const char* kind, double* out);
+
 /* ---- plans: device-resident batch pipelines -------------------------------- */
 typedef struct ssq_stft_plan ssq_stft_plan;
 /* One plan = one (dtype, N, n_fft, hop, window, fs, padtype, squeezing, gamma) configuration.

@@ -1,4 +1,5 @@
-"""CPU oracle for the ssqueeze `_rs` hot path (stft / ssq_stft / cwt / cwt_simd / ssq_cwt).
+"""CPU oracle for the ssqueeze `_rs` hot path (stft / ssq_stft / cwt / cwt_simd / ssq_cwt) and the §8(f)
+rows next to it (icwt, the wavelet helper functions).
 
 TEST INFRASTRUCTURE ONLY.  Nothing under ``ssqueeze_rs_amd/`` may import this
 module: only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
@@ -525,6 +526,188 @@ def ssq_cwt(x, wavelet: str = "gmw", scales=None, fs=None, t=None,
 def hello_from_bin() -> str:
     """lib.rs:16-19."""
     return "Hello from ssqueeze!"
+
+
+# ----------------------------------------------------------------------------
+# SURVEY §8 (f) rows: icwt and the wavelet helper functions (implemented in the reference but not
+# registered in lib.rs:25-32; advertised by src/ssqueeze/_rs.pyi:61-132)
+# ----------------------------------------------------------------------------
+def icwt(Wx, wavelet: str = "gmw", scales=None, nv=None, one_int: bool = True, x_len=None, x_mean: float = 0.0,
+         padtype: str = "reflect", rpadded: bool = False, l1_norm: bool = True) -> np.ndarray:
+    """cwt.rs:550-718.  `nv`, `padtype`, `rpadded` are accepted and unused there."""
+    Wx = np.asarray(Wx, dtype=np.complex128)
+    n_scales, n_times = Wx.shape
+    if scales is None:
+        raise ValueError("Scales must be provided")                       # :571-575
+    sc = np.asarray(scales, dtype=np.float64)
+    adm = {"morlet": 0.776, "gmw": 1.0}.get(wavelet, 1.0)                 # :578-582
+    x_length = n_times if x_len is None else int(x_len)                   # :586
+    if x_length > n_times or sc.shape[0] < n_scales:
+        raise RustPanic("index out of bounds")                            # Wx_array[[i, j]] / scales_array[i]
+    if n_scales > 1 and sc[1] > sc[0]:                                    # :593-597, :704-708
+        dj = math.log(sc[1] / sc[0])
+    else:
+        dj = 0.1
+    final_norm = (2.0 / adm) * dj
+    x = np.zeros(x_length, dtype=np.float64)
+    if one_int:                                                           # :588-627
+        for i in range(n_scales):                                         # per column: scales ascending (:620-622)
+            nf = 1.0 if l1_norm else 1.0 / math.sqrt(sc[i])               # :605-609
+            x += Wx[i, :x_length].real * nf
+        return x * final_norm + x_mean                                    # :623
+    xi = xifn(1.0, x_length)                                              # :633
+    for i in range(n_scales):                                             # :636-693 (summed ascending, :696-700)
+        psih = wavelet_fourier(xi, float(sc[i]), wavelet)
+        tmp = np.fft.fft(Wx[i, :x_length]) * np.conj(psih + 0j)           # :659-666
+        r = np.fft.ifft(tmp, norm="forward")                              # unnormalised inverse (:675)
+        sn = 1.0 / sc[i] if l1_norm else 1.0 / (math.sqrt(sc[i]) ** 2)    # :679-683
+        x += r.real * (1.0 / float(x_length)) * sn                        # :678, :685-687
+    return x * final_norm + x_mean                                        # :710-713
+
+
+def morlet(w, mu: float = 6.0, dtype: str = "float64") -> np.ndarray:
+    """wavelets/morlet.rs:22-41 via :59-77.  No `w >= 0` gate here (the hot path's inline Morlet has one and a
+    different normalisation, cwt.rs:497-520)."""
+    w = np.asarray(w, dtype=np.float64)
+    cs = (1.0 + math.exp(-(mu * mu)) - 2.0 * math.exp(-3.0 / 4.0 * (mu * mu))) ** (-0.5)     # :24
+    ks = math.exp(-0.5 * (mu * mu))                                                          # :25
+    factor = math.sqrt(2.0) * cs * math.pow(math.pi, 0.25)                                   # :33
+    out = factor * (np.exp(-0.5 * ((w - mu) * (w - mu))) - ks * np.exp(-0.5 * (w * w)))      # :37-40
+    return out.astype(np.complex128)
+
+
+def morlet_freq(n: int = 1024, scale: float = 1.0, mu: float = 6.0, dtype: str = "float64") -> np.ndarray:
+    """wavelets/morlet.rs:80-100."""
+    return morlet(xifn(scale, n), mu, dtype)
+
+
+def _time_from_freq(psih: np.ndarray) -> np.ndarray:
+    """wavelets/morlet.rs:114-141 == gmw.rs:306-333: (-1)^i spectral reversal, halve the Nyquist bin when n is even,
+    unnormalised inverse FFT, times 1/n."""
+    n = psih.shape[0]
+    p = psih * np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    if n % 2 == 0 and n > 0:
+        p[n // 2] /= 2.0
+    r = np.fft.ifft(p, norm="forward")
+    return (r.real * (1.0 / n)) + 1j * (r.imag * (1.0 / n))
+
+
+def morlet_time(n: int = 1024, scale: float = 1.0, mu: float = 6.0, dtype: str = "float64") -> np.ndarray:
+    """wavelets/morlet.rs:103-145."""
+    return _time_from_freq(morlet_freq(n, scale, mu, dtype))
+
+
+def gamma_function(x: float) -> float:
+    """wavelets/gmw.rs:172-201 (Lanczos, g = 7, 8 coefficients)."""
+    if x < 0.5:
+        return math.pi / (math.sin(math.pi * x) * gamma_function(1.0 - x))
+    p = [676.5203681218851, -1259.1392167224028, 771.32342877765313, -176.61502916214059, 12.507343278686905,
+         -0.13857109526572012, 9.9843695780195716e-6, 1.5056327351493116e-7]
+    x = x - 1.0
+    y = 0.99999999999980993
+    for i in range(len(p)):
+        y += p[i] / (x + float(i) + 1.0)
+    t = x + float(len(p)) - 0.5
+    return math.sqrt(2.0 * math.pi) * math.pow(t, x + 0.5) * math.exp(-t) * y
+
+
+def _factorial(n: int) -> float:
+    """gmw.rs:204-209."""
+    r = 1.0
+    for i in range(1, n + 1):
+        r *= float(i)
+    return r
+
+
+def _binomial(n: int, k: int) -> float:
+    """gmw.rs:212-232."""
+    if k < 0 or k > n:
+        return 0.0
+    if k == 0 or k == n:
+        return 1.0
+    if n <= 20:
+        return _factorial(n) / (_factorial(k) * _factorial(n - k))
+    c = 0.0
+    for i in range(1, k + 1):
+        c += math.log(float(n - k + i)) - math.log(float(i))
+    return math.exp(c)
+
+
+def _trunc_i32(v: float) -> int:
+    return int(v)            # `c as i32`: truncation toward zero
+
+
+def gmw(w, gamma: float = 3.0, beta: float = 60.0, norm: str = "bandpass", order: int = 0,
+        dtype: str = "float64") -> np.ndarray:
+    """wavelets/gmw.rs:236-262: validation (:246-254), then GMW::psih."""
+    if gamma <= 0.0:
+        raise ValueError("gamma must be positive")
+    if beta < 0.0:
+        raise ValueError("beta must be non-negative")
+    if order < 0:
+        raise ValueError("order must be non-negative")
+    return _gmw_psih(w, gamma, beta, norm, order)
+
+
+def _gmw_psih(w, gamma: float, beta: float, norm: str, order: int) -> np.ndarray:
+    """wavelets/gmw.rs:72-159 (norm is lower-cased, :25; anything but "bandpass" is the L2 branch)."""
+    w = np.asarray(w, dtype=np.float64)
+    bandpass = norm.lower() == "bandpass"
+    wc = math.pow(beta / gamma, 1.0 / gamma)                              # :33-35
+    r = (2.0 * beta + 1.0) / gamma                                        # :38-40
+    out = np.zeros(w.shape[0], dtype=np.float64)
+    pos = w > 0.0                                                         # :84, :100, :131
+    wp = w[pos]
+    with np.errstate(all="ignore"):
+        if order == 0:
+            if bandpass:
+                nc = 2.0 / math.exp(beta * math.log(wc) - math.pow(wc, gamma)) if wc > 0 else float("nan")   # :46-50
+                out[pos] = nc * np.exp(beta * np.log(wp) - np.power(wp, gamma))                              # :89-92
+            else:
+                nc = math.sqrt(2.0 * math.pi * gamma * math.pow(2.0, r) / gamma_function(r))                 # :52-54
+                out[pos] = nc * np.power(wp, beta) * np.exp(-np.power(wp, gamma))                            # :105-108
+        else:
+            c = r - 1.0
+            k = int(order)
+            if bandpass:
+                coeff = 2.0 * math.sqrt(gamma_function(r) * gamma_function(k + 1.0) / gamma_function(k + r))  # :119-123
+            else:
+                coeff = math.sqrt(2.0 * math.pi * gamma * math.pow(2.0, r) * gamma_function(k + 1.0) /
+                                  gamma_function(k + r))                                                      # :125-127
+            xx = 2.0 * np.power(wp, gamma)                                # :137
+            lag = np.zeros_like(wp)
+            ci = _trunc_i32(c)
+            for m in range(k + 1):                                        # :59-68
+                b = _binomial(k + ci + 1, ci + m + 1) * _binomial(k, m)
+                lag = lag + b * (((-1.0) ** m) * np.power(xx, m) / _factorial(m))
+            if bandpass:
+                e = np.exp(-beta * math.log(wc) + math.pow(wc, gamma) + beta * np.log(wp) - np.power(wp, gamma))   # :141-145
+                out[pos] = coeff * lag * e
+            else:
+                out[pos] = coeff * lag * np.power(wp, beta) * np.exp(-np.power(wp, gamma))                    # :149-153
+    return out.astype(np.complex128)
+
+
+def gmw_freq(n: int = 1024, scale: float = 1.0, gamma: float = 3.0, beta: float = 60.0, norm: str = "bandpass",
+             order: int = 0, dtype: str = "float64") -> np.ndarray:
+    """wavelets/gmw.rs:265-289 (no parameter validation on this entry)."""
+    return _gmw_psih(xifn(scale, n), gamma, beta, norm, order)
+
+
+def gmw_time(n: int = 1024, scale: float = 1.0, gamma: float = 3.0, beta: float = 60.0, norm: str = "bandpass",
+             order: int = 0, dtype: str = "float64") -> np.ndarray:
+    """wavelets/gmw.rs:292-337."""
+    return _time_from_freq(gmw_freq(n, scale, gamma, beta, norm, order, dtype))
+
+
+def gmw_center_frequency(gamma: float = 3.0, beta: float = 60.0, kind: str = "peak") -> float:
+    """wavelets/gmw.rs:340-357."""
+    if kind == "peak":
+        return math.pow(beta / gamma, 1.0 / gamma)
+    if kind == "energy":
+        return (1.0 / math.pow(2.0, 1.0 / gamma)) * (gamma_function((2.0 * beta + 2.0) / gamma) /
+                                                      gamma_function((2.0 * beta + 1.0) / gamma))
+    raise ValueError(f"Unknown center frequency kind: {kind}")
 
 
 # ----------------------------------------------------------------------------

@@ -52,6 +52,14 @@ _SIGNATURES = {
                                C.c_int, vp, vp]),
     "ssq_ssq_cwt_host": (C.c_int, [C.c_int, vp, i64, i64, C.c_int, vp, i64, C.c_double, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp, vp, vp]),
+    "ssq_icwt_host": (C.c_int, [C.c_int, vp, i64, i64, C.c_int, vp, i64, C.c_int, i64, C.c_double, C.c_int, vp]),
+    "ssq_morlet": (C.c_int, [vp, i64, C.c_double, vp]),
+    "ssq_morlet_freq": (C.c_int, [i64, C.c_double, C.c_double, vp]),
+    "ssq_morlet_time": (C.c_int, [i64, C.c_double, C.c_double, vp]),
+    "ssq_gmw": (C.c_int, [vp, i64, C.c_double, C.c_double, C.c_char_p, C.c_int, vp]),
+    "ssq_gmw_freq": (C.c_int, [i64, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_int, vp]),
+    "ssq_gmw_time": (C.c_int, [i64, C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_int, vp]),
+    "ssq_gmw_center_frequency": (C.c_int, [C.c_double, C.c_double, C.c_char_p, C.POINTER(C.c_double)]),
     "ssq_stft_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, i64, vp, i64, i64, C.c_double, C.c_int,
                                        C.c_int, C.c_double, C.c_int]),
     "ssq_stft_plan_destroy": (C.c_int, [vp]),

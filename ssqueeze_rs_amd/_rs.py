@@ -255,4 +255,86 @@ def ssq_cwt(x, wavelet="gmw", scales=None, fs=None, t=None, ssq_freqs=None, nv=3
     return out
 
 
-__all__ = ["hello_from_bin", "stft", "ssq_stft", "cwt", "cwt_simd", "ssq_cwt", "PanicException"]
+# --------------------------------------------------------------------------- icwt + wavelet helpers
+def icwt(Wx, wavelet="gmw", scales=None, nv=None, one_int=True, x_len=None, x_mean=0.0, padtype="reflect",
+         rpadded=False, l1_norm=True):
+    """rust/src/spectral/cwt.rs:550-718 (advertised by _rs.pyi:61-73).  `Wx` complex128 [n_scales, n_times]
+    (extension: complex64); returns float64 [x_len or n_times].  `nv`, `padtype`, `rpadded` are unused there too."""
+    lib = _lib.load()
+    if not isinstance(Wx, np.ndarray) or Wx.ndim != 2 or Wx.dtype not in (np.complex128, np.complex64):
+        raise TypeError("argument 'Wx': expected a 2-D complex128 array")
+    if scales is None:
+        raise ValueError("Scales must be provided")                              # :571-575
+    sc = _as_f64_vector(scales, "scales")
+    Wc = np.ascontiguousarray(Wx)
+    na, n_times = Wc.shape
+    xl = n_times if x_len is None else _usize(x_len, "x_len")
+    if xl > n_times or sc.shape[0] < na:
+        raise PanicException("index out of bounds")                              # Wx_array[[i, j]] / scales_array[i]
+    out = np.empty(xl, dtype=np.float64)
+    if xl == 0:
+        return out
+    _lib.require_gpu()
+    _call(lib.ssq_icwt_host(SSQ_F32 if Wc.dtype == np.complex64 else SSQ_F64, _ptr(Wc), na, n_times,
+                            WAVELET.get(wavelet, 0) if wavelet in WAVELET else 0, _ptr(sc), sc.shape[0],
+                            int(bool(one_int)), xl, float(x_mean), int(bool(l1_norm)), _ptr(out)))
+    return out
+
+
+def _cplx_out(n):
+    return np.empty(int(n), dtype=np.complex128)
+
+
+def morlet(w, mu=6.0, dtype="float64"):
+    """rust/src/wavelets/morlet.rs:59-77: Morlet in the frequency domain at the given `w` (complex128, imag = 0)."""
+    wv = _as_f64_vector(w, "w")
+    out = _cplx_out(wv.shape[0])
+    _call(_lib.load().ssq_morlet(_ptr(wv), wv.shape[0], float(mu), _ptr(out)))
+    return out
+
+
+def morlet_freq(n=1024, scale=1.0, mu=6.0, dtype="float64"):
+    """rust/src/wavelets/morlet.rs:80-100."""
+    out = _cplx_out(_usize(n, "n"))
+    _call(_lib.load().ssq_morlet_freq(n, float(scale), float(mu), _ptr(out)))
+    return out
+
+
+def morlet_time(n=1024, scale=1.0, mu=6.0, dtype="float64"):
+    """rust/src/wavelets/morlet.rs:103-145."""
+    out = _cplx_out(_usize(n, "n"))
+    _call(_lib.load().ssq_morlet_time(n, float(scale), float(mu), _ptr(out)))
+    return out
+
+
+def gmw(w, gamma=3.0, beta=60.0, norm="bandpass", order=0, dtype="float64"):
+    """rust/src/wavelets/gmw.rs:236-262 (ValueError for gamma <= 0, beta < 0, order < 0)."""
+    wv = _as_f64_vector(w, "w")
+    out = _cplx_out(wv.shape[0])
+    _call(_lib.load().ssq_gmw(_ptr(wv), wv.shape[0], float(gamma), float(beta), str(norm).encode(), int(order), _ptr(out)))
+    return out
+
+
+def gmw_freq(n=1024, scale=1.0, gamma=3.0, beta=60.0, norm="bandpass", order=0, dtype="float64"):
+    """rust/src/wavelets/gmw.rs:265-289."""
+    out = _cplx_out(_usize(n, "n"))
+    _call(_lib.load().ssq_gmw_freq(n, float(scale), float(gamma), float(beta), str(norm).encode(), int(order), _ptr(out)))
+    return out
+
+
+def gmw_time(n=1024, scale=1.0, gamma=3.0, beta=60.0, norm="bandpass", order=0, dtype="float64"):
+    """rust/src/wavelets/gmw.rs:292-337."""
+    out = _cplx_out(_usize(n, "n"))
+    _call(_lib.load().ssq_gmw_time(n, float(scale), float(gamma), float(beta), str(norm).encode(), int(order), _ptr(out)))
+    return out
+
+
+def gmw_center_frequency(gamma=3.0, beta=60.0, kind="peak"):
+    """rust/src/wavelets/gmw.rs:340-357 ("peak" | "energy"; anything else -> ValueError)."""
+    v = C.c_double(0.0)
+    _call(_lib.load().ssq_gmw_center_frequency(float(gamma), float(beta), str(kind).encode(), C.byref(v)))
+    return v.value
+
+
+__all__ = ["hello_from_bin", "stft", "ssq_stft", "cwt", "cwt_simd", "ssq_cwt", "icwt", "morlet", "morlet_freq",
+           "morlet_time", "gmw", "gmw_freq", "gmw_time", "gmw_center_frequency", "PanicException"]
