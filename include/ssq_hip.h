@@ -170,6 +170,17 @@ int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* plan, const void* d_x, int64_t batch,
                           void* d_Tx, void* d_dbg_Wx, void* d_dbg_dWx, void* d_dbg_wk,
                           void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- host-path caches ---------------------------------------------------------
+ * The *_host entry points keep plans (keyed by their configuration), device scratch and two streams between
+ * calls, and pipeline H2D / kernels / D2H over the signals of a batch.  Results that live in blocks of the
+ * library's pinned pool arrive by DMA without a host-side copy; `ssqueeze_rs_amd._rs` allocates its NumPy results
+ * there (the reference hands NumPy freshly allocated arrays too: ssq_stft.rs:307-312). */
+int ssq_pinned_alloc(void** ptr, int64_t bytes);         /* pooled hipHostMalloc */
+int ssq_pinned_free(void* ptr);                          /* back to the pool */
+int ssq_host_cache_limit(int64_t idle_pinned_bytes);     /* idle pinned memory the pool may keep (default 8 GiB) */
+int ssq_host_cache_stats(int64_t* live_pinned_bytes, int64_t* idle_pinned_bytes);
+int ssq_host_cache_clear(void);                          /* drop cached plans, device scratch, idle pinned blocks */
+
 /* ---- device memory / stream / event plumbing for FFI callers --------------- */
 int ssq_dev_malloc(void** ptr, int64_t bytes);
 int ssq_dev_free(void* ptr);

@@ -75,6 +75,11 @@ _SIGNATURES = {
     "ssq_cwt_plan_exec_cwt": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp, vp, vp, i64, vp]),
     "ssq_cwt_plan_exec_ssq": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                         vp, vp, vp, vp, vp, i64, vp]),
+    "ssq_pinned_alloc": (C.c_int, [C.POINTER(vp), i64]),
+    "ssq_pinned_free": (C.c_int, [vp]),
+    "ssq_host_cache_limit": (C.c_int, [i64]),
+    "ssq_host_cache_stats": (C.c_int, [C.POINTER(i64), C.POINTER(i64)]),
+    "ssq_host_cache_clear": (C.c_int, []),
     "ssq_dev_malloc": (C.c_int, [C.POINTER(vp), i64]),
     "ssq_dev_free": (C.c_int, [vp]),
     "ssq_dev_memset": (C.c_int, [vp, C.c_int, i64, vp]),
@@ -130,6 +135,37 @@ def device_count() -> int:
     n = C.c_int(0)
     rc = load().ssq_device_count(C.byref(n))
     return n.value if rc == 0 else 0
+
+
+class _PinnedBlock:
+    """Owner of one block of the library's pinned pool; returns it when the NumPy array on top of it dies."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        check(load().ssq_pinned_alloc(C.byref(self.ptr), int(nbytes)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.ssq_pinned_free(self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def pinned_empty(shape, dtype):
+    """`np.empty(shape, dtype)` in pinned host memory from the library's pool: device results land in it by DMA, no
+    page faults, no staging copy.  An ordinary writable ndarray for the caller; the block goes back to the pool when
+    the array (and every view of it) is garbage-collected.  Falls back to np.empty when no GPU is visible."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    if n == 0 or device_count() < 1:
+        return np.empty(shape, dtype=dt)
+    blk = _PinnedBlock(n)
+    raw = (C.c_char * n).from_address(blk.ptr.value)
+    raw._ssq_owner = blk                    # the ctypes array is the ndarray's base: it keeps the block alive
+    return np.frombuffer(raw, dtype=dt).reshape(shape)
 
 
 def require_gpu():

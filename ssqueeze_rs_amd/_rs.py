@@ -103,7 +103,7 @@ def stft(x, n_fft, hop_length, window, padtype):
     _lib.require_gpu()
     n_freqs = n_fft // 2 + 1
     n_frames = (N - 1) // hop + 1
-    Sx = np.empty((batch, n_freqs, n_frames), dtype=_cdtype(code))
+    Sx = _lib.pinned_empty((batch, n_freqs, n_frames), _cdtype(code))     # results arrive by DMA (no staging copy)
     freqs = np.empty(n_freqs, dtype=np.float64)
     _call(lib.ssq_stft_host(code, _ptr(xa), batch, N, _ptr(win), n_fft, hop, PAD.get(padtype, 0),
                             _ptr(Sx), _ptr(freqs)))
@@ -138,9 +138,9 @@ def ssq_stft(x, window, n_fft=None, win_len=None, hop_len=1, fs=1.0, padtype="re
     _lib.require_gpu()
     n_frames = (N - 1) // hop + 1
     cd = _cdtype(code)
-    Tx = np.empty((batch, n_freqs, n_frames), dtype=cd)
+    Tx = _lib.pinned_empty((batch, n_freqs, n_frames), cd)
     ssq_freqs = np.empty(n_freqs, dtype=np.float64)
-    dbg = [np.empty_like(Tx) for _ in range(3)] if _debug else [None, None, None]
+    dbg = [_lib.pinned_empty(Tx.shape, cd) for _ in range(3)] if _debug else [None, None, None]
     g = -1.0 if gamma is None else float(gamma)
     _call(lib.ssq_ssq_stft_host(code, _ptr(xa), batch, N, _ptr(sized), n_fft, hop, fs,
                                 PAD.get(padtype, 0), SQUEEZE.get(squeezing, 0), g,
@@ -192,8 +192,8 @@ def _cwt_impl(x, wavelet, scales, fs, t, nv, l1_norm, derivative, padtype, rpadd
     P, n1 = C.c_int64(0), C.c_int64(0)
     _call(lib.ssq_cwt_pad_len(N, C.byref(P), C.byref(n1)))
     cols = P.value if rpadded else N
-    Wx = np.empty((batch, na, cols), dtype=cd)
-    dWx = np.empty((batch, na, cols), dtype=cd) if derivative else None
+    Wx = _lib.pinned_empty((batch, na, cols), cd)
+    dWx = _lib.pinned_empty((batch, na, cols), cd) if derivative else None
     if na > 0:
         _lib.require_gpu()
         _call(lib.ssq_cwt_host(code, _ptr(xa), batch, N, WAVELET.get(wavelet, 0), _ptr(sc), na, dt,
@@ -238,9 +238,9 @@ def ssq_cwt(x, wavelet="gmw", scales=None, fs=None, t=None, ssq_freqs=None, nv=3
         raise PanicException("index out of bounds: the len is 0 but the index is 18446744073709551615")  # :459
     _lib.require_gpu()
     cd = _cdtype(code)
-    Tx = np.empty((batch, na, N), dtype=cd)
+    Tx = _lib.pinned_empty((batch, na, N), cd)
     freqs = np.empty(na, dtype=np.float64)
-    dbg = [np.empty_like(Tx) for _ in range(3)] if _debug else [None, None, None]
+    dbg = [_lib.pinned_empty(Tx.shape, cd) for _ in range(3)] if _debug else [None, None, None]
     g = -1.0 if gamma is None else float(gamma)
     _call(lib.ssq_ssq_cwt_host(code, _ptr(xa), batch, N, WAVELET.get(wavelet, 0), _ptr(sc), na, dt,
                                1 if ssq_freqs == "linear" else 0, 1 if maprange == "maximal" else 0,

@@ -8,7 +8,10 @@
 #include <vector>
 
 #include "../../include/ssq_hip.h"
+#include <mutex>
+
 #include "cwt_kernels.h"
+#include "host_cache.h"
 #include "host_math.h"
 
 using namespace ssq;
@@ -442,47 +445,123 @@ int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* pl, const void* d_x, int64_t batch, int 
                                 d_dbg_dWx, d_dbg_wk, (char*)d_workspace, (hipStream_t)stream);
 }
 
-// ---- host-pointer entry points -------------------------------------------------
+}  // extern "C"
+
+// ---- host-pointer entry points: cached plan (the wavelet table alone is ~1 GB at C4), cached device buffers,
+// ---- D2H of signal b on a second stream while signal b+1 computes -----------------------------------------------
 namespace {
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { hipFree(p); }
-  int alloc(long long bytes) {
-    if (bytes <= 0) bytes = 16;
-    SSQ_HIP(hipMalloc(&p, (size_t)bytes));
+
+struct CwtKey {
+  int dtype, wavelet, padtype;
+  int64_t n_signal;
+  double dt;
+  std::vector<double> scales;
+  bool operator==(const CwtKey& o) const {
+    return dtype == o.dtype && wavelet == o.wavelet && padtype == o.padtype && n_signal == o.n_signal && dt == o.dt &&
+           scales == o.scales;
+  }
+};
+struct CachedCwt {
+  CwtKey key;
+  ssq_cwt_plan* pl;
+  int dev;
+};
+std::vector<CachedCwt> g_cwt_plans;            // guarded by hostpath::mutex()
+constexpr size_t kMaxCwtPlans = 2;
+
+int cached_cwt_plan(const CwtKey& key, ssq_cwt_plan** out) {
+  int dev = 0;
+  SSQ_HIP(hipGetDevice(&dev));
+  for (size_t i = 0; i < g_cwt_plans.size(); ++i) {
+    if (g_cwt_plans[i].dev == dev && g_cwt_plans[i].key == key) {
+      CachedCwt c = g_cwt_plans[i];
+      g_cwt_plans.erase(g_cwt_plans.begin() + (long)i);
+      g_cwt_plans.insert(g_cwt_plans.begin(), c);
+      *out = c.pl;
+      return 0;
+    }
+  }
+  while (g_cwt_plans.size() >= kMaxCwtPlans) {     // make room first: the tables are large
+    ssq_cwt_plan_destroy(g_cwt_plans.back().pl);
+    g_cwt_plans.pop_back();
+  }
+  ssq_cwt_plan* pl = nullptr;
+  if (int rc = ssq_cwt_plan_create(&pl, key.dtype, key.n_signal, key.wavelet, key.scales.data(),
+                                   (int64_t)key.scales.size(), key.dt, key.padtype))
+    return rc;
+  g_cwt_plans.insert(g_cwt_plans.begin(), CachedCwt{key, pl, dev});
+  *out = pl;
+  return 0;
+}
+
+struct EventPair {
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  ~EventPair() {
+    for (auto e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
+  int init() {
+    for (auto& e : ev) SSQ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
   }
 };
-struct PlanGuard {
-  ssq_cwt_plan* pl = nullptr;
-  ~PlanGuard() { ssq_cwt_plan_destroy(pl); }
-};
+
 }  // namespace
+
+namespace ssq {
+namespace hostpath {
+void clear_cwt_plans() {
+  for (auto& c : g_cwt_plans) ssq_cwt_plan_destroy(c.pl);
+  g_cwt_plans.clear();
+}
+}  // namespace hostpath
+}  // namespace ssq
+
+extern "C" {
 
 int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, const double* scales,
                  int64_t na, double dt, int l1_norm, int padtype, int rpadded, void* Wx, void* dWx) {
   if (!x || !Wx) SSQ_FAIL("x or Wx is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
   if (na == 0) return 0;
-  PlanGuard g;
-  if (int rc = ssq_cwt_plan_create(&g.pl, dtype, n_signal, wavelet, scales, na, dt, padtype)) return rc;
-  const long long esz = dtype == SSQ_F32 ? 4 : 8;
-  const long long cols = rpadded ? g.pl->P : n_signal;
-  const long long out_bytes = batch * na * cols * 2 * esz;
-  DevBuf dx, dW, ddW, ws;
-  if (int rc = dx.alloc(batch * n_signal * esz)) return rc;
-  if (int rc = dW.alloc(out_bytes)) return rc;
-  if (dWx)
-    if (int rc = ddW.alloc(out_bytes)) return rc;
-  const long long wsb = ssq_cwt_plan_workspace_bytes(g.pl, batch);
-  if (int rc = ws.alloc(wsb)) return rc;
-  SSQ_HIP(hipMemcpy(dx.p, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
-  if (int rc = ssq_cwt_plan_exec_cwt(g.pl, dx.p, batch, l1_norm, rpadded, dW.p, dWx ? ddW.p : nullptr, ws.p, wsb,
-                                     nullptr))
+  if (!scales) SSQ_FAIL("scales is NULL");
+  std::lock_guard<std::mutex> lk(hostpath::mutex());
+  ssq_cwt_plan* pl = nullptr;
+  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na)}, &pl))
     return rc;
-  SSQ_HIP(hipDeviceSynchronize());
-  SSQ_HIP(hipMemcpy(Wx, dW.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
-  if (dWx) SSQ_HIP(hipMemcpy(dWx, ddW.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  const long long esz = dtype == SSQ_F32 ? 4 : 8;
+  const long long cols = rpadded ? pl->P : n_signal;
+  const long long out1 = na * cols * 2 * esz, in1 = n_signal * esz;
+  void *dx = nullptr, *dW = nullptr, *ddW = nullptr, *ws = nullptr;
+  if (int rc = hostpath::scratch(hostpath::SLOT_X, batch * in1, &dx)) return rc;
+  if (int rc = hostpath::scratch(hostpath::SLOT_OUT, 2 * out1, &dW)) return rc;
+  if (dWx)
+    if (int rc = hostpath::scratch(hostpath::SLOT_A, 2 * out1, &ddW)) return rc;
+  const long long wsb = ssq_cwt_plan_workspace_bytes(pl, 1);
+  if (int rc = hostpath::scratch(hostpath::SLOT_WS0, wsb, &ws)) return rc;
+  hipStream_t s0 = hostpath::stream(0), s1 = hostpath::stream(1);
+  EventPair done, freed;
+  if (int rc = done.init()) return rc;
+  if (int rc = freed.init()) return rc;
+  SSQ_HIP(hipMemcpyAsync(dx, x, (size_t)(batch * in1), hipMemcpyHostToDevice, s0));
+  int rc = 0;
+  for (int64_t b = 0; b < batch && rc == 0; ++b) {
+    const int k = (int)(b & 1);
+    char* oW = (char*)dW + (long long)k * out1;
+    char* odW = dWx ? (char*)ddW + (long long)k * out1 : nullptr;
+    if (b >= 2) SSQ_HIP(hipStreamWaitEvent(s0, freed.ev[k], 0));          // slot k was downloaded
+    rc = ssq_cwt_plan_exec_cwt(pl, (char*)dx + b * in1, 1, l1_norm, rpadded, oW, odW, ws, wsb, s0);
+    if (rc) break;
+    SSQ_HIP(hipEventRecord(done.ev[k], s0));
+    SSQ_HIP(hipStreamWaitEvent(s1, done.ev[k], 0));
+    SSQ_HIP(hipMemcpyAsync((char*)Wx + b * out1, oW, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    if (dWx) SSQ_HIP(hipMemcpyAsync((char*)dWx + b * out1, odW, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    SSQ_HIP(hipEventRecord(freed.ev[k], s1));
+  }
+  const hipError_t e0 = hipStreamSynchronize(s0), e1 = hipStreamSynchronize(s1);
+  if (rc) return rc;
+  SSQ_HIP(e0);
+  SSQ_HIP(e1);
   return 0;
 }
 
@@ -493,33 +572,52 @@ int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, 
   if (!x || !Tx) SSQ_FAIL("x or Tx is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
   if (na <= 0) SSQ_FAIL("index out of bounds: scales is empty (ssq_cwt.rs:459)");
-  PlanGuard g;
-  if (int rc = ssq_cwt_plan_create(&g.pl, dtype, n_signal, wavelet, scales, na, dt, padtype)) return rc;
-  const long long esz = dtype == SSQ_F32 ? 4 : 8;
-  const long long out_bytes = batch * na * n_signal * 2 * esz;
-  DevBuf dx, dT, d1, d2, d3, ws;
-  if (int rc = dx.alloc(batch * n_signal * esz)) return rc;
-  if (int rc = dT.alloc(out_bytes)) return rc;
-  if (dbg_Wx)
-    if (int rc = d1.alloc(out_bytes)) return rc;
-  if (dbg_dWx)
-    if (int rc = d2.alloc(out_bytes)) return rc;
-  if (dbg_wk)
-    if (int rc = d3.alloc(out_bytes)) return rc;
-  const long long wsb = ssq_cwt_plan_workspace_bytes(g.pl, batch);
-  if (int rc = ws.alloc(wsb)) return rc;
-  SSQ_HIP(hipMemcpy(dx.p, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
-  if (int rc = ssq_cwt_plan_exec_ssq(g.pl, dx.p, batch, freq_dist, maprange, squeezing, flipud, gamma, dT.p,
-                                     dbg_Wx ? d1.p : nullptr, dbg_dWx ? d2.p : nullptr,
-                                     dbg_wk ? d3.p : nullptr, ws.p, wsb, nullptr))
+  if (!scales) SSQ_FAIL("scales is NULL");
+  std::lock_guard<std::mutex> lk(hostpath::mutex());
+  ssq_cwt_plan* pl = nullptr;
+  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na)}, &pl))
     return rc;
-  SSQ_HIP(hipDeviceSynchronize());
-  SSQ_HIP(hipMemcpy(Tx, dT.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
-  if (dbg_Wx) SSQ_HIP(hipMemcpy(dbg_Wx, d1.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
-  if (dbg_dWx) SSQ_HIP(hipMemcpy(dbg_dWx, d2.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
-  if (dbg_wk) SSQ_HIP(hipMemcpy(dbg_wk, d3.p, (size_t)out_bytes, hipMemcpyDeviceToHost));
+  const long long esz = dtype == SSQ_F32 ? 4 : 8;
+  const long long out1 = na * n_signal * 2 * esz, in1 = n_signal * esz;
+  void *dx = nullptr, *dT = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *ws = nullptr;
+  if (int rc = hostpath::scratch(hostpath::SLOT_X, batch * in1, &dx)) return rc;
+  if (int rc = hostpath::scratch(hostpath::SLOT_OUT, 2 * out1, &dT)) return rc;
+  if (dbg_Wx)
+    if (int rc = hostpath::scratch(hostpath::SLOT_A, 2 * out1, &d1)) return rc;
+  if (dbg_dWx)
+    if (int rc = hostpath::scratch(hostpath::SLOT_B, 2 * out1, &d2)) return rc;
+  if (dbg_wk)
+    if (int rc = hostpath::scratch(hostpath::SLOT_C, 2 * out1, &d3)) return rc;
+  const long long wsb = ssq_cwt_plan_workspace_bytes(pl, 1);
+  if (int rc = hostpath::scratch(hostpath::SLOT_WS0, wsb, &ws)) return rc;
+  hipStream_t s0 = hostpath::stream(0), s1 = hostpath::stream(1);
+  EventPair done, freed;
+  if (int rc = done.init()) return rc;
+  if (int rc = freed.init()) return rc;
+  SSQ_HIP(hipMemcpyAsync(dx, x, (size_t)(batch * in1), hipMemcpyHostToDevice, s0));
+  int rc = 0;
+  for (int64_t b = 0; b < batch && rc == 0; ++b) {
+    const int k = (int)(b & 1);
+    const long long so = (long long)k * out1;
+    if (b >= 2) SSQ_HIP(hipStreamWaitEvent(s0, freed.ev[k], 0));
+    rc = ssq_cwt_plan_exec_ssq(pl, (char*)dx + b * in1, 1, freq_dist, maprange, squeezing, flipud, gamma, (char*)dT + so,
+                               dbg_Wx ? (char*)d1 + so : nullptr, dbg_dWx ? (char*)d2 + so : nullptr,
+                               dbg_wk ? (char*)d3 + so : nullptr, ws, wsb, s0);
+    if (rc) break;
+    SSQ_HIP(hipEventRecord(done.ev[k], s0));
+    SSQ_HIP(hipStreamWaitEvent(s1, done.ev[k], 0));
+    SSQ_HIP(hipMemcpyAsync((char*)Tx + b * out1, (char*)dT + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    if (dbg_Wx) SSQ_HIP(hipMemcpyAsync((char*)dbg_Wx + b * out1, (char*)d1 + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    if (dbg_dWx) SSQ_HIP(hipMemcpyAsync((char*)dbg_dWx + b * out1, (char*)d2 + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    if (dbg_wk) SSQ_HIP(hipMemcpyAsync((char*)dbg_wk + b * out1, (char*)d3 + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
+    SSQ_HIP(hipEventRecord(freed.ev[k], s1));
+  }
+  const hipError_t e0 = hipStreamSynchronize(s0), e1 = hipStreamSynchronize(s1);
+  if (rc) return rc;
+  SSQ_HIP(e0);
+  SSQ_HIP(e1);
   if (ssq_freqs)
-    if (int rc = ssq_cwt_ssq_freqs(scales, na, n_signal, dt, maprange, freq_dist, ssq_freqs)) return rc;
+    if (int rc2 = ssq_cwt_ssq_freqs(scales, na, n_signal, dt, maprange, freq_dist, ssq_freqs)) return rc2;
   return 0;
 }
 

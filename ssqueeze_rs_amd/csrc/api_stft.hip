@@ -8,6 +8,10 @@
 #include <vector>
 
 #include "../../include/ssq_hip.h"
+#include <algorithm>
+#include <mutex>
+
+#include "host_cache.h"
 #include "host_math.h"
 #include "stft_kernels.h"
 
@@ -281,54 +285,122 @@ int ssq_stft_plan_exec_strided(ssq_stft_plan* pl, int out_kind, const void* d_x,
   return exec_any(pl, out_kind, d_x, n_groups * group, d_out, d_workspace, workspace_bytes, stream, lay);
 }
 
-// Shared body of the two host entry points: upload x, run the requested outputs, download.
+}  // extern "C"
+
+// ---- host-pointer entry points: cached plans, cached device buffers, a two-stream pipeline ----------------------
+namespace {
+
+struct PlanKey {
+  int dtype, padtype, squeezing;
+  int64_t n_signal, n_fft, hop;
+  double fs, gamma;
+  std::vector<double> window;
+  bool operator==(const PlanKey& o) const {
+    return dtype == o.dtype && padtype == o.padtype && squeezing == o.squeezing && n_signal == o.n_signal &&
+           n_fft == o.n_fft && hop == o.hop && fs == o.fs && gamma == o.gamma && window == o.window;
+  }
+};
+struct CachedPlan {
+  PlanKey key;
+  ssq_stft_plan* pl;
+  int dev;
+};
+std::vector<CachedPlan> g_plans;               // most recently used first; guarded by hostpath::mutex()
+constexpr size_t kMaxPlans = 8;
+
+int cached_plan(const PlanKey& key, ssq_stft_plan** out) {
+  int dev = 0;
+  SSQ_HIP(hipGetDevice(&dev));
+  for (size_t i = 0; i < g_plans.size(); ++i) {
+    if (g_plans[i].dev == dev && g_plans[i].key == key) {
+      CachedPlan c = g_plans[i];
+      g_plans.erase(g_plans.begin() + (long)i);
+      g_plans.insert(g_plans.begin(), c);
+      *out = c.pl;
+      return 0;
+    }
+  }
+  ssq_stft_plan* pl = nullptr;
+  if (int rc = ssq_stft_plan_create(&pl, key.dtype, key.n_signal, key.window.data(), key.n_fft, key.hop, key.fs,
+                                    key.padtype, key.squeezing, key.gamma, 0))
+    return rc;
+  g_plans.insert(g_plans.begin(), CachedPlan{key, pl, dev});
+  while (g_plans.size() > kMaxPlans) {
+    ssq_stft_plan_destroy(g_plans.back().pl);
+    g_plans.pop_back();
+  }
+  *out = pl;
+  return 0;
+}
+
+}  // namespace
+
+namespace ssq {
+namespace hostpath {
+void clear_stft_plans() {
+  for (auto& c : g_plans) ssq_stft_plan_destroy(c.pl);
+  g_plans.clear();
+}
+}  // namespace hostpath
+}  // namespace ssq
+
+// Shared body of the two host entry points.  The batch is cut into groups of signals; group g runs on stream g % 2:
+// H2D of its samples, the kernels of every requested output, D2H of each result -- so one group's copies overlap the
+// other's kernels and, with results in pinned memory (ssq_pinned_alloc: what `_rs.*` hands to NumPy), the host
+// thread only ever waits for the upload staging of pageable inputs.
 static int run_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
                     int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing, double gamma,
                     int n_out, const int* kinds, void* const* outs) {
   if (!x) SSQ_FAIL("x is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
+  if (!window) SSQ_FAIL("window is NULL");
+  if (n_fft <= 0) SSQ_FAIL("n_fft must be positive");
+  std::lock_guard<std::mutex> lk(hostpath::mutex());
+  PlanKey key{dtype, padtype, squeezing, n_signal, n_fft, hop, fs, gamma, std::vector<double>(window, window + n_fft)};
   ssq_stft_plan* pl = nullptr;
-  if (int rc = ssq_stft_plan_create(&pl, dtype, n_signal, window, n_fft, hop, fs, padtype, squeezing, gamma, 0))
-    return rc;
+  if (int rc = cached_plan(key, &pl)) return rc;
   const int64_t esz = dtype == SSQ_F32 ? 4 : 8;
-  const int64_t bins = batch * (int64_t)pl->n_freqs * pl->n_frames;
-  void *d_x = nullptr, *d_out = nullptr, *d_ws = nullptr;
+  const int64_t bins1 = (int64_t)pl->n_freqs * pl->n_frames;            // per signal
+  const int64_t in1 = n_signal * esz, out1 = bins1 * 2 * esz;
+  // group size: enough work per launch for small signals, a few MB per copy for big ones
+  int64_t grp = (8LL << 20) / (out1 > 0 ? out1 : 1);
+  if (grp < 1) grp = 1;
+  if (grp > batch) grp = batch;
+  int64_t ws1 = 0;
+  for (int i = 0; i < n_out; ++i)
+    if (outs[i]) ws1 = std::max<int64_t>(ws1, ssq_stft_plan_workspace_bytes(pl, grp, kinds[i]));
+  void *d_x = nullptr, *d_out = nullptr, *d_ws[2] = {nullptr, nullptr};
+  if (int rc = hostpath::scratch(hostpath::SLOT_X, batch * in1, &d_x)) return rc;
+  if (int rc = hostpath::scratch(hostpath::SLOT_OUT, 2 * grp * out1, &d_out)) return rc;     // one slot per stream
+  if (ws1 > 0) {
+    if (int rc = hostpath::scratch(hostpath::SLOT_WS0, ws1, &d_ws[0])) return rc;
+    if (int rc = hostpath::scratch(hostpath::SLOT_WS1, ws1, &d_ws[1])) return rc;
+  }
+  hipStream_t st[2] = {hostpath::stream(0), hostpath::stream(1)};
+  if (!st[0] || !st[1]) SSQ_FAIL("hipStreamCreate failed");
   int rc = 0;
-  int64_t ws = 0;
-  for (int i = 0; i < n_out; ++i) {
-    const int64_t w = ssq_stft_plan_workspace_bytes(pl, batch, kinds[i]);
-    if (outs[i] && w > ws) ws = w;
+  int64_t g = 0;
+  for (int64_t b0 = 0; b0 < batch && rc == 0; b0 += grp, ++g) {
+    const int64_t nb = std::min<int64_t>(grp, batch - b0);
+    const int s = (int)(g & 1);
+    char* dxg = (char*)d_x + b0 * in1;
+    char* dog = (char*)d_out + (int64_t)s * grp * out1;
+    SSQ_HIP(hipMemcpyAsync(dxg, (const char*)x + b0 * in1, (size_t)(nb * in1), hipMemcpyHostToDevice, st[s]));
+    for (int i = 0; i < n_out && rc == 0; ++i) {
+      if (!outs[i]) continue;
+      rc = ssq_stft_plan_exec(pl, kinds[i], dxg, nb, dog, d_ws[s], ws1, st[s]);
+      if (rc) break;
+      SSQ_HIP(hipMemcpyAsync((char*)outs[i] + b0 * out1, dog, (size_t)(nb * out1), hipMemcpyDeviceToHost, st[s]));
+    }
   }
-  auto cleanup = [&]() {
-    hipFree(d_x);
-    hipFree(d_out);
-    hipFree(d_ws);
-    ssq_stft_plan_destroy(pl);
-  };
-#define SSQ_TRY(call)                                                        \
-  do {                                                                       \
-    hipError_t e__ = (call);                                                 \
-    if (e__ != hipSuccess) {                                                 \
-      ssq::set_error(std::string(#call) + ": " + hipGetErrorString(e__));    \
-      cleanup();                                                             \
-      return 2;                                                              \
-    }                                                                        \
-  } while (0)
-  SSQ_TRY(hipMalloc(&d_x, (size_t)(batch * n_signal * esz)));
-  SSQ_TRY(hipMalloc(&d_out, (size_t)(bins * 2 * esz)));
-  if (ws > 0) SSQ_TRY(hipMalloc(&d_ws, (size_t)ws));
-  SSQ_TRY(hipMemcpy(d_x, x, (size_t)(batch * n_signal * esz), hipMemcpyHostToDevice));
-  for (int i = 0; i < n_out && rc == 0; ++i) {
-    if (!outs[i]) continue;
-    rc = ssq_stft_plan_exec(pl, kinds[i], d_x, batch, d_out, d_ws, ws, nullptr);
-    if (rc) break;
-    SSQ_TRY(hipDeviceSynchronize());
-    SSQ_TRY(hipMemcpy(outs[i], d_out, (size_t)(bins * 2 * esz), hipMemcpyDeviceToHost));
-  }
-#undef SSQ_TRY
-  cleanup();
-  return rc;
+  const hipError_t e0 = hipStreamSynchronize(st[0]), e1 = hipStreamSynchronize(st[1]);
+  if (rc) return rc;
+  SSQ_HIP(e0);
+  SSQ_HIP(e1);
+  return 0;
 }
+
+extern "C" {
 
 int ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
                   int64_t n_fft, int64_t hop, int padtype, void* Sx, double* freqs) {

@@ -34,6 +34,16 @@ def test_signatures_and_defaults_match_pyo3_signatures():
                                           padtype="reflect", squeezing="sum", maprange="peak", difftype="trig",
                                           gamma=None, vectorized=True, flipud=True)   # ssq_cwt.rs:245-260
     assert list(inspect.signature(_rs.ssq_stft).parameters)[:2] == ["x", "window"]
+    # the functions the stubs advertise beyond lib.rs (src/ssqueeze/_rs.pyi:61-132; cwt.rs:551, morlet.rs:60,:81,:104,
+    # gmw.rs:237,:266,:293,:341)
+    assert _defaults(_rs.icwt) == dict(wavelet="gmw", scales=None, nv=None, one_int=True, x_len=None, x_mean=0.0,
+                                       padtype="reflect", rpadded=False, l1_norm=True)
+    assert _defaults(_rs.morlet) == dict(mu=6.0, dtype="float64")
+    assert _defaults(_rs.morlet_freq) == _defaults(_rs.morlet_time) == dict(n=1024, scale=1.0, mu=6.0, dtype="float64")
+    assert _defaults(_rs.gmw) == dict(gamma=3.0, beta=60.0, norm="bandpass", order=0, dtype="float64")
+    assert _defaults(_rs.gmw_freq) == _defaults(_rs.gmw_time) == dict(n=1024, scale=1.0, gamma=3.0, beta=60.0,
+                                                                      norm="bandpass", order=0, dtype="float64")
+    assert _defaults(_rs.gmw_center_frequency) == dict(gamma=3.0, beta=60.0, kind="peak")
 
 
 def test_argument_errors_raised_before_any_gpu_work():
