@@ -39,6 +39,19 @@ struct ssq_cwt_plan {
   void* d_scale_l2 = nullptr;  // [na] sqrt(a)/P
   double* d_scales = nullptr;
   int chunk = 1;               // scales per inverse-FFT chunk
+  // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool can_fuse_ssq() const { return two_step && !naive && na <= 32767; }
+  // SSQ_CWT_FUSED=1 selects the fused step B / mode Z (phase transform + bin in the store phase, Wx + 16-bit row index
+  // out, dWx never in memory: 37 % less traffic between the transforms and the reassignment).  Measured on C4
+  // (profiles/r02_ab_cwt_fused.txt): 8.64 ms against 8.16 ms for the unfused narrow step B with two blocks per CU --
+  // the tile kernel's phases add, so the extra store-phase arithmetic costs more than the bytes it saves.  Default off.
+  bool fused_ssq() const {
+    if (!can_fuse_ssq()) return false;
+    const char* e = std::getenv("SSQ_CWT_FUSED");
+    return e && std::atoi(e) != 0;
+  }
 };
 
 namespace {
@@ -146,8 +159,8 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   off += align(pl->two_step ? (long long)pl->chunk * 2 * pl->P * csz : 0);
   L.w = off;
   off += align((long long)pl->na * pl->N * csz);
-  L.dw = off;
-  off += align((long long)pl->na * pl->N * csz);
+  L.dw = off;                  // fused ssq path: the 16-bit row indices K live here instead of dWx
+  off += align((long long)pl->na * pl->N * csz);     // dWx (unfused path) or the 16-bit row indices (fused path)
   L.total = off;
   return L;
 }
@@ -252,6 +265,47 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
   return 0;
 }
 
+// ssq path of two-step plans: step A as above, then the FUSED step B / mode Z (Wx + row index out, dWx stays on chip)
+template <typename T>
+int run_inverse_ssq(const ssq_cwt_plan* pl, CwtDev<T> p, const CwtSsqDev<T>& q, cpx<T>* Wx, short* K, cpx<T>* dWx_dbg,
+                    hipStream_t st) {
+  p.Wx = Wx;
+  p.K = K;
+  p.dWx = dWx_dbg;
+  p.n_kinds = 2;
+  p.rpadded = 0;
+  p.cols = pl->N;
+  p.out_scale = (const T*)pl->d_scale_l1;                 // ssq_cwt is always L1 (ssq_cwt.rs:405)
+  int s0 = 0;
+  while (s0 < pl->na) {
+    const int lq = pl->zoom_logq[(size_t)s0];
+    int s1 = s0 + 1;
+    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq) ++s1;
+    if (lq > 0) {
+      CwtDev<T> z = p;
+      z.scale0 = s0;
+      z.n_transforms = (s1 - s0) * 2;
+      z.log_p2 = lq;
+      z.log_p1 = pl->logP - lq;
+      z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
+      z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
+      SSQ_HIP(launch_cwt_tile_ssq<T>(CWT_INV_Z, z, q, st));
+    } else {
+      for (int c0 = s0; c0 < s1; c0 += pl->chunk) {
+        const int ns = (s1 - c0 < pl->chunk) ? s1 - c0 : pl->chunk;
+        p.scale0 = c0;
+        p.n_transforms = ns * 2;
+        p.tw_m = (const cpx<T>*)pl->d_tw1;
+        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
+        p.tw_m = (const cpx<T>*)pl->d_tw2;
+        SSQ_HIP(launch_cwt_tile_ssq<T>(CWT_INV_B, p, q, st));
+      }
+    }
+    s0 = s1;
+  }
+  return 0;
+}
+
 template <typename T>
 int exec_cwt_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, bool l1, bool rpadded, void* d_Wx,
                    void* d_dWx, char* ws, hipStream_t st) {
@@ -296,17 +350,59 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   q.gamma = (T)(gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma);       // ssq_cwt.rs:438-441
   q.leb_val = (T)(1.0 / (double)n);
   const long long plane = (long long)n * pl->N;
+  if (pl->fused_ssq()) {
+    if (!pl->side) {
+      SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+      SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+      SSQ_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+    }
+    for (long long b = 0; b < batch; ++b) {
+      CwtDev<T> p = base_dev<T>(pl, ws);
+      cpx<T>* W = (cpx<T>*)(ws + L.w);
+      short* K = (short*)(ws + L.dw);
+      q.Wx = W;
+      q.dWx = nullptr;
+      q.Tx = (cpx<T>*)d_Tx + b * plane;
+      q.wk = d_dbg_wk ? (cpx<T>*)d_dbg_wk + b * plane : nullptr;
+      // fork: clear this signal's Tx (2.15 GB at C4) beside the transforms instead of in front of the reassignment
+      SSQ_HIP(hipEventRecord(pl->ev_fork, st));
+      SSQ_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+      SSQ_HIP(hipMemsetAsync(q.Tx, 0, (size_t)plane * sizeof(cpx<T>), pl->side));
+      SSQ_HIP(hipEventRecord(pl->ev_join, pl->side));
+      if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
+      if (int rc = run_inverse_ssq<T>(pl, p, q, W, K, d_dbg_dWx ? (cpx<T>*)d_dbg_dWx + b * plane : nullptr, st)) return rc;
+      SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));            // join
+      SSQ_HIP(launch_cwt_reassign_k<T>(q, K, st));
+      if (d_dbg_Wx)
+        SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
+                               hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+  }
+  const bool side_clear = pl->can_fuse_ssq();             // big plans: clear Tx beside the transforms here too
+  if (side_clear && !pl->side) {
+    SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
+    SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+    SSQ_HIP(hipEventCreateWithFlags(&pl->ev_join, hipEventDisableTiming));
+  }
   for (long long b = 0; b < batch; ++b) {
     CwtDev<T> p = base_dev<T>(pl, ws);
+    q.Tx = (cpx<T>*)d_Tx + b * plane;
+    if (side_clear) {
+      SSQ_HIP(hipEventRecord(pl->ev_fork, st));
+      SSQ_HIP(hipStreamWaitEvent(pl->side, pl->ev_fork, 0));
+      SSQ_HIP(hipMemsetAsync(q.Tx, 0, (size_t)plane * sizeof(cpx<T>), pl->side));
+      SSQ_HIP(hipEventRecord(pl->ev_join, pl->side));
+    }
     if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
     cpx<T>* W = (cpx<T>*)(ws + L.w);
     cpx<T>* dW = (cpx<T>*)(ws + L.dw);
     if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st)) return rc;   // ssq_cwt is always L1 (:405)
     q.Wx = W;
     q.dWx = dW;
-    q.Tx = (cpx<T>*)d_Tx + b * plane;
     q.wk = d_dbg_wk ? (cpx<T>*)d_dbg_wk + b * plane : nullptr;
-    SSQ_HIP(launch_cwt_reassign<T>(q, st));
+    if (side_clear) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
+    SSQ_HIP(launch_cwt_reassign<T>(q, st, !side_clear));
     if (d_dbg_Wx)
       SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
                              hipMemcpyDeviceToDevice, st));
@@ -407,6 +503,9 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_scale_l1);
   hipFree(pl->d_scale_l2);
   hipFree(pl->d_scales);
+  if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
+  if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
+  if (pl->side) (void)hipStreamDestroy(pl->side);
   delete pl;
   return 0;
 }

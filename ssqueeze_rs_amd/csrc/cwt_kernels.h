@@ -30,6 +30,7 @@ struct CwtDev {
   const int* band;       // [na] psih_s[k] == 0 for k >= band[s] (<= P/2 + 1)
   cpx<T>* Wx;            // [na][cols]
   cpx<T>* dWx;           // [na][cols] or NULL
+  short* K;              // fused ssq kernels: [na][N] Tx row of every (scale, time) element, -1 = skipped
   long long n_signal;
   long long P;           // padded length (power of two)
   long long n1;          // (P - N)/2                                 (cwt.rs:98)
@@ -77,6 +78,17 @@ struct CwtSsqDev {
   T leb_val;             // 1/na                                      (ssq_cwt.rs:201-204)
 };
 template <typename T>
-hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream);
+hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream, bool clear);   // clear: zero Tx first
+
+// Fused synchrosqueezing variants of inverse step B / mode Z (two-step plans): one block runs BOTH transforms (Wx and
+// dWx, ssq_cwt.rs:387-402) of one scale for its rows, applies the phase transform (ssq_cwt.rs:15-47) and the bin
+// formula (:160-196) in the store phase and writes Wx plus a 16-bit row index -- dWx never reaches memory.
+// p.n_transforms = 2 * scales of the launch; q carries the binning parameters and the optional (w, k) hook buffer.
+template <typename T>
+hipError_t launch_cwt_tile_ssq(int mode, const CwtDev<T>& p, const CwtSsqDev<T>& q, hipStream_t stream);
+// Tx from (Wx, K): one thread per time column, scales ascending, runs of equal rows summed in registers.
+// Tx must be zero on entry (the caller clears it on a side stream while the transforms run).
+template <typename T>
+hipError_t launch_cwt_reassign_k(const CwtSsqDev<T>& p, const short* K, hipStream_t stream);
 
 }  // namespace ssq

@@ -490,6 +490,275 @@ __device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cp
   return kk;
 }
 
+#ifndef SSQ_CWT_WIDE_STORE
+#define SSQ_CWT_WIDE_STORE 0
+#endif
+// ---------------------------------------------------------------- fused ssq step B / mode Z ----
+// See cwt_kernels.h.  The LDS holds the same 2*Cf rows as the unfused tile (Cf rows of the Wx transform, then Cf rows
+// of the dWx transform of the SAME scale); loads, FFT rounds and the transposed read-back are those of
+// cwt_tile_kernel, the store phase pairs element (c, k2) of the two halves.
+template <typename T, int LOGM, int MODE>
+__global__ __launch_bounds__((tile_threads<T>())) void cwt_tile_ssq_kernel(CwtDev<T> p, CwtSsqDev<T> q) {
+  using K = TileCfg<T, LOGM, false>;
+  constexpr int M = K::M, L = K::L, C2 = K::C, CF = K::C / 2, ROWP = K::ROWP;
+  constexpr int kTileThreads = K::THREADS;
+  static_assert(MODE == CWT_INV_B || MODE == CWT_INV_Z, "fused modes");
+  static_assert(K::C >= 2 && K::C % 2 == 0, "two halves");
+  constexpr bool TW_REGS = (sizeof(T) == 4) && (C2 / K::TPR > 1);
+  constexpr bool stepZ = (MODE == CWT_INV_Z);
+  constexpr int PER = C2 * M / kTileThreads;
+  constexpr int U = PER < SSQ_CWT_U ? PER : SSQ_CWT_U;
+  static_assert(PER % U == 0, "whole batches");
+  constexpr bool USE_F1 = K::F1 && stepZ;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[USE_F1 ? K::LDS_TOTAL : K::LDS_BYTES];
+  cpx<T>* rows = reinterpret_cast<cpx<T>*>(smem);
+  cpx<T>* f1 = reinterpret_cast<cpx<T>*>(smem + K::LDS_BYTES);
+
+  const int tid = threadIdx.x;
+  const int s_local = blockIdx.y;                        // transforms 2*s_local (Wx) and 2*s_local + 1 (dWx)
+  const long long tile = blockIdx.x;
+  const long long P2 = 1LL << p.log_p2;
+  const long long P1 = 1LL << p.log_p1;
+  const long long t0 = tile * CF;                        // first row (B) / residue (Z)
+
+  if constexpr (USE_F1) {
+    for (int k = tid; k < M; k += kTileThreads) f1[k] = twiddle_P(p, t0 * k);
+    __syncthreads();
+  }
+  auto fetch = [&](int e) -> cpx<T> {
+    const int r = e / M, m = e % M;
+    const int kind = r / CF, c = r % CF;
+    const int tr = 2 * s_local + kind;
+    if constexpr (!stepZ) {
+      if (t0 + c >= P1) return {(T)0, (T)0};
+      return p.ybuf[(long long)tr * p.P + (t0 + c) * P2 + m];
+    } else {
+      long long d = t0 + c;
+      const bool live = d < P1;
+      if (!live) d = 0;
+      cpx<T> w;
+      if constexpr (USE_F1) w = cmul(f1[m], p.tw_f2[c * M + m]);
+      else w = twiddle_P(p, (long long)m * d);
+      cpx<T> v = cmul(conj_if(load_spectrum(p, tr, m), true), w);
+      if (!live) v = {(T)0, (T)0};
+      return v;
+    }
+  };
+#pragma unroll 1
+  for (int i0 = 0; i0 < PER; i0 += U) {
+    cpx<T> buf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) buf[u] = fetch(tid + (i0 + u) * kTileThreads);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + (i0 + u) * kTileThreads;
+      rows[(e / M) * ROWP + exch_phys(e % M)] = buf[u];
+    }
+  }
+  __syncthreads();
+  {
+    const int slot = tid / L;
+    const int t = tid % L;
+    cpx<T> twr[3][16];
+    if constexpr (TW_REGS) {
+#pragma unroll
+      for (int P = 1; P < num_passes(LOGM); ++P) {
+        const int R = pass_radix(LOGM, P), NS = pass_ns(LOGM, P), NB = 16 / R;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+#pragma unroll
+          for (int m = 1; m < 16; ++m) {
+            if (b < NB && m < R) {
+              const int k = (t + L * b) & (NS - 1);
+              twr[P - 1][b + m * NB] = p.tw_m[k * m * (M / (NS * R))];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll 1
+    for (int round = 0; round < C2 / K::TPR; ++round) {
+      cpx<T>* row = rows + (round * K::TPR + slot) * ROWP;
+      cpx<T> v[16];
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) v[qq] = row[exch_phys(t + L * qq)];
+      frame_sync<K::MULTIWAVE>();
+      fft_pass<T, LOGM, 0, false, TW_REGS, K::MULTIWAVE>(v, row, twr, p.tw_m, t);
+#pragma unroll
+      for (int qq = 0; qq < 16; ++qq) row[exch_phys(t + L * qq)] = v[qq];
+    }
+  }
+  __syncthreads();
+  // store: thread -> one output index k2 and ALL CF rows c of both halves: time n = t0 + c + P1*k2 (B) / d + D*m (Z),
+  // so a thread owns CF contiguous samples and writes them as 16-byte pieces (Wx: CF*8 bytes, K: CF*2 bytes)
+  const int s = p.scale0 + s_local;
+  const T sc = p.out_scale[s];
+  constexpr int SWEEPS = (M + kTileThreads - 1) / kTileThreads;
+  constexpr bool WIDE = SSQ_CWT_WIDE_STORE && (CF <= 8);   // per-thread contiguous pieces: measured 3 % slower on C4
+  if constexpr (!WIDE) {
+    // short transforms (many rows per tile): element (c fastest, k2) per thread, as cwt_tile_kernel stores
+    constexpr int PERS = CF * M / kTileThreads;
+    static_assert((CF * M) % kTileThreads == 0, "whole store sweeps");
+#pragma unroll 4
+    for (int i = 0; i < PERS; ++i) {
+      const int e = tid + i * kTileThreads;
+      const int c = e % CF, k2 = e / CF;
+      if (t0 + c >= P1) continue;
+      const long long n = t0 + c + P1 * k2;
+      if (n < p.n1 || n >= p.n1 + p.n_signal) continue;                  // unpad (ssq_cwt.rs:434-435)
+      cpx<T> a = conj_if(rows[c * ROWP + exch_phys(k2)], true);
+      cpx<T> b = conj_if(rows[(CF + c) * ROWP + exch_phys(k2)], true);
+      a = {a.x * sc, a.y * sc};
+      b = {b.x * sc, b.y * sc};
+      T w;
+      const int kk = reassign_bin(q, a, b, w);
+      const long long o = (long long)s * p.n_signal + (n - p.n1);
+      p.Wx[o] = a;
+      p.K[o] = (short)kk;
+      if (p.dWx) p.dWx[o] = b;
+      if (q.wk) q.wk[o] = {w, (T)kk};
+    }
+    return;
+  }
+  constexpr int CW = WIDE ? CF : 1;                       // (array extents of the wide path only)
+  const bool whole = (t0 + CF <= P1);
+#pragma unroll 1
+  for (int i = 0; i < SWEEPS; ++i) {
+    const int k2 = tid + i * kTileThreads;
+    if (k2 >= M) break;
+    const long long nb = t0 + P1 * (long long)k2;                       // time of row c = 0
+    if (nb + CW <= p.n1 || nb >= p.n1 + p.n_signal) continue;            // wholly inside the padding
+    cpx<T> Wv[CW];
+    short kv[CW];
+    T wv[CW];
+    cpx<T> dv[CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      cpx<T> a = conj_if(rows[c * ROWP + exch_phys(k2)], true);
+      cpx<T> b = conj_if(rows[(CF + c) * ROWP + exch_phys(k2)], true);
+      a = {a.x * sc, a.y * sc};                                          // 1/P (ssq_cwt.rs:405-418)
+      b = {b.x * sc, b.y * sc};
+      Wv[c] = a;
+      dv[c] = b;
+      kv[c] = (short)reassign_bin(q, a, b, wv[c]);
+    }
+    const long long o = (long long)s * p.n_signal + (nb - p.n1);
+    const bool full = whole && nb >= p.n1 && nb + CW <= p.n1 + p.n_signal;
+    if (full && !p.dWx && !q.wk && sizeof(T) == 4 && CW % 2 == 0 && ((o & 1) == 0)) {
+      // 16-byte stores: two complex floats at a time; CF shorts in 16-byte (CF = 8) or 8-byte pieces
+      float4* dst = reinterpret_cast<float4*>(p.Wx + o);
+#pragma unroll
+      for (int c = 0; c < CW; c += 2) dst[c / 2] = make_float4((float)Wv[c].x, (float)Wv[c].y, (float)Wv[c + 1].x, (float)Wv[c + 1].y);
+      if constexpr (CW == 8) {
+        if ((o & 7) == 0) {
+          int4 pk;
+          pk.x = (unsigned short)kv[0] | ((unsigned)(unsigned short)kv[1] << 16);
+          pk.y = (unsigned short)kv[2] | ((unsigned)(unsigned short)kv[3] << 16);
+          pk.z = (unsigned short)kv[4] | ((unsigned)(unsigned short)kv[5] << 16);
+          pk.w = (unsigned short)kv[6] | ((unsigned)(unsigned short)kv[7] << 16);
+          *reinterpret_cast<int4*>(p.K + o) = pk;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CW; c += 2)
+            *reinterpret_cast<unsigned*>(p.K + o + c) = (unsigned short)kv[c] | ((unsigned)(unsigned short)kv[c + 1] << 16);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CW; c += 2)
+          *reinterpret_cast<unsigned*>(p.K + o + c) = (unsigned short)kv[c] | ((unsigned)(unsigned short)kv[c + 1] << 16);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+        const long long n = nb + c;
+        if (t0 + c >= P1 || n < p.n1 || n >= p.n1 + p.n_signal) continue;    // unpad (ssq_cwt.rs:434-435)
+        p.Wx[o + c] = Wv[c];
+        p.K[o + c] = kv[c];
+        if (p.dWx) p.dWx[o + c] = dv[c];
+        if (q.wk) q.wk[o + c] = {wv[c], (T)kv[c]};
+      }
+    }
+  }
+}
+
+template <typename T, int LOGM, int MODE>
+static hipError_t launch_tile_ssq_mode(const CwtDev<T>& p, const CwtSsqDev<T>& q, hipStream_t stream) {
+  using K = TileCfg<T, LOGM, false>;
+  constexpr int CF = K::C / 2;
+  const dim3 grid((unsigned)(((1LL << p.log_p1) + CF - 1) / CF), (unsigned)(p.n_transforms / 2), 1);
+  hipLaunchKernelGGL((cwt_tile_ssq_kernel<T, LOGM, MODE>), grid, dim3(K::THREADS), 0, stream, p, q);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_cwt_tile_ssq(int mode, const CwtDev<T>& p, const CwtSsqDev<T>& q, hipStream_t stream) {
+#define SSQ_CASE(LM)                                                                         \
+  case LM:                                                                                   \
+    return mode == CWT_INV_Z ? launch_tile_ssq_mode<T, LM, CWT_INV_Z>(p, q, stream)          \
+                             : launch_tile_ssq_mode<T, LM, CWT_INV_B>(p, q, stream);
+  switch (p.log_p2) {
+    SSQ_CASE(4) SSQ_CASE(5) SSQ_CASE(6) SSQ_CASE(7) SSQ_CASE(8) SSQ_CASE(9) SSQ_CASE(10) SSQ_CASE(11) SSQ_CASE(12)
+  }
+#undef SSQ_CASE
+  return hipErrorInvalidValue;
+}
+
+// Tx from (Wx, K): see cwt_kernels.h
+template <typename T>
+__global__ void cwt_reassign_k_kernel(CwtSsqDev<T> p, const short* __restrict__ K) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p.N) return;
+  const cpx<T>* __restrict__ Wxp = p.Wx + j;
+  const short* __restrict__ Kp = K + j;
+  constexpr int UN = 8;
+  int k_cur = -1;
+  cpx<T> acc = {(T)0, (T)0};
+  auto flush = [&]() {
+    if (k_cur >= 0) {
+      const long long d = (long long)k_cur * p.N + j;
+      cpx<T> t = p.Tx[d];
+      t.x += acc.x;
+      t.y += acc.y;
+      p.Tx[d] = t;
+    }
+  };
+  for (int i0 = 0; i0 < p.na; i0 += UN) {
+    cpx<T> Wb[UN];
+    int kb[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
+      Wb[u] = Wxp[(long long)ii * p.N];
+      kb[u] = Kp[(long long)ii * p.N];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (i0 + u >= p.na) break;
+      const int kk = kb[u];
+      if (kk != k_cur) {
+        flush();
+        k_cur = kk;
+        acc = {(T)0, (T)0};
+      }
+      if (kk >= 0) {
+        if (p.squeezing == 1) {
+          acc.x += p.leb_val;
+        } else {
+          acc.x += Wb[u].x;
+          acc.y += Wb[u].y;
+        }
+      }
+    }
+  }
+  flush();
+}
+
+template <typename T>
+hipError_t launch_cwt_reassign_k(const CwtSsqDev<T>& p, const short* K, hipStream_t stream) {
+  hipLaunchKernelGGL(cwt_reassign_k_kernel<T>, dim3((unsigned)((p.N + 63) / 64)), dim3(64), 0, stream, p, K);
+  return hipGetLastError();
+}
+
 // One thread owns one time column and walks the scales in ascending order (no atomics, deterministic),
 // read-modify-writing a zero-filled Tx; runs of scales that land in the same row are summed in registers first (the
 // reference adds them to the row one by one: same sum up to the order of two roundings).  (An LDS-resident Tx tile [na][64 columns] with the rows split
@@ -552,9 +821,11 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
 }
 
 template <typename T>
-hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream) {
-  const hipError_t e = hipMemsetAsync(p.Tx, 0, (size_t)p.na * (size_t)p.N * sizeof(cpx<T>), stream);
-  if (e != hipSuccess) return e;
+hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream, bool clear) {
+  if (clear) {
+    const hipError_t e = hipMemsetAsync(p.Tx, 0, (size_t)p.na * (size_t)p.N * sizeof(cpx<T>), stream);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(cwt_reassign_kernel<T>, dim3((unsigned)((p.N + 63) / 64)), dim3(64), 0, stream, p);
   return hipGetLastError();
 }
@@ -581,7 +852,9 @@ int cwt_tile_rows(int logm) {
   template hipError_t launch_wavelet_table<T>(T*, const double*, int, long long, int, hipStream_t);   \
   template hipError_t launch_cwt_naive_fwd<T>(const CwtDev<T>&, hipStream_t);                         \
   template hipError_t launch_cwt_naive_inv<T>(const CwtDev<T>&, int, hipStream_t);                    \
-  template hipError_t launch_cwt_reassign<T>(const CwtSsqDev<T>&, hipStream_t);
+  template hipError_t launch_cwt_reassign<T>(const CwtSsqDev<T>&, hipStream_t, bool);                 \
+  template hipError_t launch_cwt_tile_ssq<T>(int, const CwtDev<T>&, const CwtSsqDev<T>&, hipStream_t); \
+  template hipError_t launch_cwt_reassign_k<T>(const CwtSsqDev<T>&, const short*, hipStream_t);
 SSQ_INST(float)
 SSQ_INST(double)
 #undef SSQ_INST

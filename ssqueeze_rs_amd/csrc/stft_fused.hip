@@ -650,6 +650,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_XHALF
 #define SSQ_XHALF 1                // 1: exchange 1 of the 16-wave kernel by register halves (full-width LDS stores)
 #endif
+#ifndef SSQ_LATE_PREFETCH
+#define SSQ_LATE_PREFETCH 1        // 1: issue the next tile's sample loads after exchange 1 (keeps the kernel out of scratch)
+#endif
 #ifndef SSQ_DPP_FUSE
 #define SSQ_DPP_FUSE 0             // 1: lane-pair merge sums as v_add_u32_dpp (inline asm) instead of v_mov_dpp + v_add
 #endif
@@ -840,7 +843,9 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       ++nsig;
     }
     const bool has_next = nsig < n_sig;
+#if !SSQ_LATE_PREFETCH
     if (has_next && !SSQ_ABL(32)) load_frame(nsig, tile_frame0(njt), xn);
+#endif
     SSQ_STAMP(1);
 
     // ---- pass 0: radix 16 over elements t + 64q ----
@@ -885,6 +890,12 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = nv[q];
     }
+#if SSQ_LATE_PREFETCH
+    // the next tile's samples: issued only now, after exchange 1 -- during the exchange both the old and the new
+    // register set of the frame are live, and 16 more registers in flight there push the kernel into scratch; the rest
+    // of this tile (pass 1, pass 2, epilogue, read-out: > 10k cycles) still covers the HBM latency many times over
+    if (has_next && !SSQ_ABL(32)) load_frame(nsig, tile_frame0(njt), xn);
+#endif
     // ---- pass 1: twiddle W_256^(k m), radix 16 ----
     fft_compute<T, 10, 1, false, false, true>(v, twr_unused, tw1, t);
 #ifdef SSQ_SENS

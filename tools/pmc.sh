@@ -17,7 +17,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --no-cpu-baseline --no-secondary --no-validate --distinct 16 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
