@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <mutex>
 
+#include "fft_generic.h"
 #include "host_cache.h"
 #include "host_math.h"
 #include "stft_kernels.h"
@@ -24,6 +25,11 @@ struct ssq_stft_plan {
   int padtype = 0, squeezing = 0;
   double fs = 1.0, gamma = 0.0;
   bool fused = false;
+  bool fft_path = false;           // unfused, but through the batched any-length device FFT instead of direct sums
+  int fft_len = 0;                 // length of the fused kernel's transforms: n_fft, or m >= 2*n_fft - 1 in Bluestein mode
+  bool blue = false;
+  void* d_blue_b = nullptr;        // Bluestein: spectrum of the chirp filter / m
+  void* d_blue_post = nullptr;     // Bluestein: output chirp
   int tile_frames = 0;
   int cu_count = 256;
   // host-side fp64 quantities (reference expressions)
@@ -44,22 +50,50 @@ template <typename T>
 int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::vector<double>& gdfs) {
   const int n = pl->n_fft;
   const long double PI = 3.14159265358979323846264338327950288L;
-  std::vector<cpx<T>> tw((size_t)n), win2((size_t)n);
+  const int m = pl->fft_len > 0 ? pl->fft_len : n;             // fused kernel's transform length
+  std::vector<cpx<T>> tw((size_t)m), win2((size_t)m, cpx<T>{(T)0, (T)0});
   std::vector<double> twre((size_t)n), twim((size_t)n);
   for (int i = 0; i < n; ++i) {
     const long double ang = 2.0L * PI * (long double)i / (long double)n;
     twre[i] = (double)cosl(ang);
     twim[i] = (double)(-sinl(ang));
-    tw[i] = {(T)twre[i], (T)twim[i]};
-    win2[i] = {(T)(0.5 * g[i]), (T)(0.5 * gdfs[i] * pl->alpha)};   // halved: the unpack then needs no scaling
+  }
+  for (int i = 0; i < m; ++i) {
+    const long double ang = 2.0L * PI * (long double)i / (long double)m;
+    tw[i] = {(T)cosl(ang), (T)(-sinl(ang))};
+  }
+  std::vector<host::cd> chirp((size_t)n);                      // exp(-i*pi*j^2/n), j^2 reduced mod 2n
+  if (pl->blue) {
+    for (long long j = 0; j < n; ++j) {
+      const long double a = -PI * (long double)((j * j) % (2LL * n)) / (long double)n;
+      chirp[j] = host::cd((double)cosl(a), (double)sinl(a));
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    host::cd w(0.5 * g[i], 0.5 * gdfs[i] * pl->alpha);         // halved: the unpack then needs no scaling
+    if (pl->blue) w *= chirp[i];                               // x*w*chirp: still one real-by-complex multiply per sample
+    win2[i] = {(T)w.real(), (T)w.imag()};
+  }
+  if (pl->blue) {
+    std::vector<host::cd> B((size_t)m, host::cd(0, 0));
+    B[0] = std::conj(chirp[0]);
+    for (int j = 1; j < n; ++j) B[j] = B[m - j] = std::conj(chirp[j]);
+    host::fft_pow2(B, -1);
+    std::vector<cpx<T>> bh((size_t)m), post((size_t)n);
+    for (int i = 0; i < m; ++i) bh[i] = {(T)(B[i].real() / (double)m), (T)(B[i].imag() / (double)m)};
+    for (int i = 0; i < n; ++i) post[i] = {(T)chirp[i].real(), (T)chirp[i].imag()};
+    SSQ_HIP(hipMalloc(&pl->d_blue_b, sizeof(cpx<T>) * m));
+    SSQ_HIP(hipMalloc(&pl->d_blue_post, sizeof(cpx<T>) * n));
+    SSQ_HIP(hipMemcpy(pl->d_blue_b, bh.data(), sizeof(cpx<T>) * m, hipMemcpyHostToDevice));
+    SSQ_HIP(hipMemcpy(pl->d_blue_post, post.data(), sizeof(cpx<T>) * n, hipMemcpyHostToDevice));
   }
   std::vector<T> fr((size_t)pl->n_freqs);
   for (int i = 0; i < pl->n_freqs; ++i) fr[i] = (T)pl->ssq_freqs[i];
-  SSQ_HIP(hipMalloc(&pl->d_tw, sizeof(cpx<T>) * n));
-  SSQ_HIP(hipMalloc(&pl->d_win2, sizeof(cpx<T>) * n));
+  SSQ_HIP(hipMalloc(&pl->d_tw, sizeof(cpx<T>) * m));
+  SSQ_HIP(hipMalloc(&pl->d_win2, sizeof(cpx<T>) * m));
   SSQ_HIP(hipMalloc(&pl->d_ssq_freqs, sizeof(T) * pl->n_freqs));
-  SSQ_HIP(hipMemcpy(pl->d_tw, tw.data(), sizeof(cpx<T>) * n, hipMemcpyHostToDevice));
-  SSQ_HIP(hipMemcpy(pl->d_win2, win2.data(), sizeof(cpx<T>) * n, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_tw, tw.data(), sizeof(cpx<T>) * m, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_win2, win2.data(), sizeof(cpx<T>) * m, hipMemcpyHostToDevice));
   SSQ_HIP(hipMemcpy(pl->d_ssq_freqs, fr.data(), sizeof(T) * pl->n_freqs, hipMemcpyHostToDevice));
   SSQ_HIP(hipMalloc((void**)&pl->d_g, sizeof(double) * n));
   SSQ_HIP(hipMalloc((void**)&pl->d_gd, sizeof(double) * n));
@@ -111,6 +145,9 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.inv_alpha = (T)(1.0 / pl->alpha);
   p.two_pi_eff = (T)(6.283185307179586 * (pl->fused ? pl->alpha : 1.0));
   p.leb_unit = (T)(1.0 / (double)pl->n_freqs);
+  p.n_eff = pl->fused ? (pl->blue ? pl->n_fft : pl->fft_len) : pl->n_fft;
+  p.blue_b = (const cpx<T>*)pl->d_blue_b;
+  p.blue_post = (const cpx<T>*)pl->d_blue_post;
   {
     // keep  <=>  den >= g2 (fp32 values).  With BIG = 1/ulp(g2): (den - g2)*BIG is 0 at equality and <= -1 for every
     // representable den < g2, so clamp(den*BIG + (1 - g2*BIG)) is exactly the 0/1 mask (g2*BIG is an integer < 2^24).
@@ -141,14 +178,31 @@ int exec_typed(ssq_stft_plan* pl, int out_kind, const void* d_x, long long batch
                void* d_ws, long long ws_bytes, hipStream_t stream, const SigLayout& lay) {
   StftDev<T> p = make_dev<T>(pl, out_kind, d_x, d_out, batch, lay);
   if (pl->fused) {
-    SSQ_HIP(launch_stft_fused<T>(p, pl->n_fft, pl->cu_count, batch, stream));
+    SSQ_HIP(launch_stft_fused<T>(p, pl->fft_len, pl->cu_count, batch, stream));
     return 0;
   }
   const long long bins = batch * (long long)pl->n_freqs * pl->n_frames;
   const long long need = ssq_stft_plan_workspace_bytes(pl, batch, out_kind);
-  if (need > 0 && (!d_ws || ws_bytes < need)) SSQ_FAIL("workspace too small for the generic STFT path");
+  if (need > 0 && (!d_ws || ws_bytes < need)) SSQ_FAIL("workspace too small for the unfused STFT path");
   GenericTabs tabs{pl->d_g, pl->d_gd, pl->d_twre, pl->d_twim};
   cpx<T>* ws = (cpx<T>*)d_ws;
+  if (pl->fft_path) {
+    // workspace: [Sx bins][dSx bins] (as the direct-sum path, when the output is not Sx itself), then Z and the FFT work
+    const bool need_d = out_kind != SSQ_OUT_SX;
+    cpx<T>* Sx = out_kind == SSQ_OUT_SX ? (cpx<T>*)d_out : ws;
+    cpx<T>* dSx = need_d ? (out_kind == SSQ_OUT_DSX ? (cpx<T>*)d_out : ws + bins) : nullptr;
+    cpx<T>* Z = ws + (out_kind == SSQ_OUT_SX ? 0 : (out_kind == SSQ_OUT_DSX ? bins : 2 * bins));
+    cpx<T>* work = Z + (long long)pl->n_frames * pl->n_fft;
+    const long long per = (long long)pl->n_freqs * pl->n_frames;
+    for (long long b = 0; b < batch; ++b)
+      SSQ_HIP(launch_fft_frames<T>(p, b, pl->n_fft, tabs, pl->alpha, Z, work, Sx + b * per, dSx ? dSx + b * per : nullptr,
+                                   stream));
+    if (out_kind == SSQ_OUT_TX || out_kind == SSQ_OUT_WK) {
+      SSQ_HIP(hipMemsetAsync(d_out, 0, (size_t)bins * sizeof(cpx<T>), stream));
+      SSQ_HIP(launch_reassign_cols<T>(p, Sx, dSx, batch, stream));
+    }
+    return 0;
+  }
   if (out_kind == SSQ_OUT_SX) {
     SSQ_HIP(launch_dft_frames<T>(p, batch, pl->n_fft, tabs, (cpx<T>*)d_out, nullptr, stream));
   } else if (out_kind == SSQ_OUT_DSX) {
@@ -219,8 +273,21 @@ int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, cons
     }
   }
   const bool f32 = dtype == SSQ_F32;
+  pl->fft_len = (int)n_fft;
   pl->fused = !force_generic && (f32 ? fused_supported<float>((int)n_fft) : fused_supported<double>((int)n_fft));
-  pl->tile_frames = pl->fused ? (f32 ? fused_tile_frames<float>((int)n_fft) : fused_tile_frames<double>((int)n_fft)) : 1;
+  if (!pl->fused && !force_generic && !host::is_pow2(n_fft) && n_fft >= 24 && n_fft <= 2048) {
+    // rustfft plans any length (stft.rs:43-44): lengths that are not a power of two run Bluestein's chirp-z inside the
+    // fused kernel, through two of its power-of-two transforms of length m >= 2*n_fft - 1 (m <= 4096)
+    int m = 64;
+    while (m < 2 * (int)n_fft - 1) m <<= 1;
+    pl->fft_len = m;
+    pl->blue = true;
+    pl->fused = true;
+  }
+  pl->tile_frames = pl->fused ? (f32 ? fused_tile_frames<float>(pl->fft_len) : fused_tile_frames<double>(pl->fft_len)) : 1;
+  // everything else that is long enough to matter: the batched any-length device FFT (force_generic keeps the direct
+  // sums as the independent second implementation of the parity tests)
+  pl->fft_path = !pl->fused && !force_generic && n_fft >= 24;
   int rc = f32 ? upload_tables<float>(pl, g, gd) : upload_tables<double>(pl, g, gd);
   if (rc) {
     ssq_stft_plan_destroy(pl);
@@ -235,6 +302,8 @@ int ssq_stft_plan_destroy(ssq_stft_plan* pl) {
   hipFree(pl->d_tw);
   hipFree(pl->d_win2);
   hipFree(pl->d_ssq_freqs);
+  hipFree(pl->d_blue_b);
+  hipFree(pl->d_blue_post);
   hipFree(pl->d_g);
   hipFree(pl->d_gd);
   hipFree(pl->d_twre);
@@ -249,9 +318,11 @@ int64_t ssq_stft_plan_workspace_bytes(const ssq_stft_plan* pl, int64_t batch, in
   if (!pl || pl->fused) return 0;
   const int64_t elem = (pl->dtype == SSQ_F32 ? 8 : 16);
   const int64_t bins = batch * (int64_t)pl->n_freqs * pl->n_frames;
-  if (out_kind == SSQ_OUT_SX) return 0;
-  if (out_kind == SSQ_OUT_DSX) return bins * elem;
-  return 2 * bins * elem;
+  int64_t extra = 0;
+  if (pl->fft_path) extra = ((int64_t)pl->n_frames * pl->n_fft + fft_work_elems(pl->n_fft, pl->n_frames)) * elem;
+  if (out_kind == SSQ_OUT_SX) return extra;
+  if (out_kind == SSQ_OUT_DSX) return bins * elem + extra;
+  return 2 * bins * elem + extra;
 }
 
 static int exec_any(ssq_stft_plan* pl, int out_kind, const void* d_x, int64_t batch, void* d_out,

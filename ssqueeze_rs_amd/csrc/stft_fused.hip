@@ -214,11 +214,16 @@ __device__ __forceinline__ FrameItem<T> make_frame(const StftDev<T>& p, const Ti
   return w;
 }
 
-template <typename T, int LOGN, bool EDGE>
+template <typename T, int LOGN, bool EDGE, bool BLUE = false>
 __device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem& tl, const FrameItem<T>& w,
-                                             T (&xv)[16]) {
+                                             T (&xv)[16], int t = 0) {
   constexpr int L = FusedCfg<T, LOGN>::L;
-  if constexpr (!EDGE) {
+  if constexpr (BLUE) {
+    // only the n_eff samples of the frame are read (the table's zero padding must not meet a NaN beyond it)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      xv[q] = (w.valid && t + L * q < p.n_eff) ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+  } else if constexpr (!EDGE) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
   } else {
@@ -269,11 +274,15 @@ __device__ __forceinline__ unsigned long long ssq_stamp() {
 // EDGE = true : the few tiles per signal that touch a boundary (padding by index mirroring).
 // WKDBG (test hook, SSQ_OUT_WK): the TXONLY epilogue stores ITS OWN (w, k) of every bin instead of scattering, so the
 // tests observe the bins of the very arithmetic that serves SSQ_OUT_TX (k = -1 where the bin is skipped).
-template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB, bool WKDBG = false>
+// BLUE: Bluestein mode (any n_fft = p.n_eff with 2*n_eff - 1 <= N): chirp folded into the window table, FFT, multiply by
+// the chirp filter's spectrum, second FFT (the inverse, on conjugated data), output chirp; bins and their partners are
+// then Z[k], Z[(n - k) mod n], k < n_freqs = n_eff/2 + 1 (fetched through the exchange row: no lane symmetry here).
+template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB, bool WKDBG = false, bool BLUE = false>
 __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
   using C = FusedCfg<T, LOGN>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
   constexpr bool MULTIWAVE = (C::WPF > 1);
+  static_assert(!BLUE || EDGE, "Bluestein mode runs the edge-capable loader (masked samples)");
   // Staggering a wave's two frames (fft_pass_pair) measured SLOWER here (4.77 vs 3.56 ms): the second
   // frame's registers push the kernel into scratch.  Kept behind this switch for the next round.
   constexpr bool PAIR = false && TXONLY && !MULTIWAVE && (sizeof(T) == 4) && (C::ITERS % 2 == 0);
@@ -368,11 +377,11 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   T xn[NFW][16];      // samples of the current item
   T xb[16];           // samples of the next item
   cur[0] = make_frame<T, LOGN, EDGE>(p, i0.tl, i0.ig, slot, t);
-  load_samples<T, LOGN, EDGE>(p, i0.tl, cur[0], xn[0]);
+  load_samples<T, LOGN, EDGE, BLUE>(p, i0.tl, cur[0], xn[0], t);
   FrameItem<T> fr1 = cur[0];
   if (i1.ok) {
     fr1 = make_frame<T, LOGN, EDGE>(p, i1.tl, i1.ig, slot, t);
-    load_samples<T, LOGN, EDGE>(p, i1.tl, fr1, xb);
+    load_samples<T, LOGN, EDGE, BLUE>(p, i1.tl, fr1, xb, t);
   }
 #ifdef SSQ_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -400,7 +409,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
     FrameItem<T> fr2 = fr1;
     if (i2.ok) {
       fr2 = make_frame<T, LOGN, EDGE>(p, i2.tl, i2.ig, slot, t);
-      if (!SSQ_ABL(1)) load_samples<T, LOGN, EDGE>(p, i2.tl, fr2, xb);
+      if (!SSQ_ABL(1)) load_samples<T, LOGN, EDGE, BLUE>(p, i2.tl, fr2, xb, t);
     }
 
     SSQ_STAMP(1);
@@ -409,13 +418,42 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       else fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
     }
     // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
+    if constexpr (BLUE) {
+      // Y * B^ (B^ carries the 1/m), conjugate, forward FFT again = conj of the inverse transform, output chirp
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const cpx<T> y = cmul(v[0][q], p.blue_b[t + L * q]);
+        v[0][q] = {y.x, -y.y};
+      }
+      if constexpr (MULTIWAVE) __syncthreads();          // the exchange row is reused by the second transform
+      fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = t + L * q;
+        const cpx<T> c = (k < p.n_eff) ? p.blue_post[k] : cpx<T>{(T)0, (T)0};
+        v[0][q] = cmul(cpx<T>{v[0][q].x, -v[0][q].y}, c);
+      }
+    }
 
     SSQ_STAMP(2);
     // ---- partner Z[N-k] for the bins this lane owns: k = t + L*q, q < 8 (+ k = N/2 on t == 0)
     cpx<T> zp[NFW][9];
 #pragma unroll
     for (int f = 0; f < NFW; ++f) {
-      if constexpr (!MULTIWAVE) {
+      if constexpr (BLUE) {
+        frame_sync<MULTIWAVE>();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[f][q];
+        frame_sync<MULTIWAVE>();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = t + L * q;
+          const int kp = (k == 0 || k >= p.n_eff) ? 0 : p.n_eff - k;       // (n - k) mod n
+          zp[f][q] = exch[exch_phys(kp)];
+        }
+        zp[f][8] = v[f][8];
+        frame_sync<MULTIWAVE>();
+      } else if constexpr (!MULTIWAVE) {
         const int src = (lane - t) + ((L - t) & (L - 1));
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -472,6 +510,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             float m = fma_clamp01(den, p.keep_big, p.keep_bias) * fma_clamp01(w, 0.0f, 1.0f);
             if (EDGE) m *= lane_on;
             if (q == 8) m *= (t == 0) ? 1.0f : 0.0f;                           // bin N/2 lives on lane 0 only
+            if constexpr (BLUE) m *= (q < 8 && t + L * q < p.n_freqs) ? 1.0f : 0.0f;   // bins of the n_eff-point transform
             if (SSQ_ABL(8)) m = lane_on;
             const cpx<T> c = LEB ? cpx<T>{p.leb_unit * m, 0.0f} : cpx<T>{S.x * m, S.y * m};   // weight (:292-296)
             cv[q] = c;
@@ -496,6 +535,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             T w;
             bool keep = phase_bin<T>(p, k, S, dS, w, kk);
             keep = keep && cur[f].valid && (q < 8 || t == 0);
+            if constexpr (BLUE) keep = keep && q < 8 && k < p.n_freqs;
             cpx<T> c = LEB ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
             c.x = keep ? c.x : (T)0;
             c.y = keep ? c.y : (T)0;
@@ -521,7 +561,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         if constexpr (WKDBG) {
 #pragma unroll
           for (int q = 0; q < 9; ++q) {
-            if ((q < 8 || t == 0) && cur[f].valid) {
+            if ((q < 8 || t == 0) && cur[f].valid && (!BLUE || (q < 8 && t + L * q < p.n_freqs))) {
               const int o = (t + L * q) * PITCH + fl;
               tile_re[o] = as_int<T>(wdbg[q]);
               tile_im[o] = as_int<T>((T)kdbg[q]);
@@ -548,6 +588,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           if (q == 8 && t != 0) break;
           if (!cur[f].valid) continue;
           const int k = t + L * q;
+          if (BLUE && (q == 8 || k >= p.n_freqs)) continue;
           const cpx<T> zk = v[f][q], zn = zp[f][q];
           const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
           const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};
@@ -583,7 +624,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         const int f = tid % F;
         const int k0 = tid / F;
         cpx<T>* __restrict__ og =
-            p.out + tl.sig * (long long)NF * p.n_frames + tl.frame0 + f + (long long)k0 * p.n_frames;
+            p.out + tl.sig * (long long)p.n_freqs * p.n_frames + tl.frame0 + f + (long long)k0 * p.n_frames;
         const long long gstep = (long long)RSTEP * p.n_frames;
         const bool fvalid = (tl.frame0 + f < p.n_frames) && !SSQ_ABL(32);
         const T sc = (TXONLY && !WKDBG) ? col_scale[f] : (T)1;
@@ -597,7 +638,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           cpx<T> val;
           if constexpr (TXONLY && !WKDBG) val = {(T)ire * sc, (T)iim * sc};
           else val = {from_int<T>(ire), from_int<T>(iim)};
-          if (store) og[j * gstep] = val;
+          if (store && (!BLUE || k0 + j * RSTEP < p.n_freqs)) og[j * gstep] = val;
         };
         if (fvalid) {
 #pragma unroll 8
@@ -1112,7 +1153,7 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
       const char* e = std::getenv("SSQ_HIOCC");
       return e ? std::atoi(e) : SSQ_HIOCC_DEFAULT;
     }();
-    if (p0.out_kind == 0 || p0.out_kind == 3) hiocc = mode;      // SSQ_OUT_WK: the (w, k) hook of the kernel that serves Tx
+    if ((p0.out_kind == 0 || p0.out_kind == 3) && p0.n_eff == C::N) hiocc = mode;   // SSQ_OUT_WK: the (w, k) hook of the kernel that serves Tx
   }
   const int TF = hiocc == 2 ? 8 : (hiocc == 1 ? 16 : C::F);   // frames per tile of the kernel that will run
   // interior tiles [lo, hi): every frame of the tile reads only inside the signal
@@ -1125,6 +1166,24 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
   if (hi > full) hi = full;
   if (lo > tps_all) lo = tps_all;
   if (hi < lo) hi = lo;
+  if (p0.n_eff != C::N) {
+    // Bluestein mode: one launch of the edge-capable loader over all tiles (the transform, not the loader, bounds it)
+    StftDev<T> p = p0;
+    p.ta0 = 0;
+    p.ta_n = tps_all;
+    p.tb0 = 0;
+    p.tiles_per_signal = tps_all;
+    p.total_tiles = (long long)tps_all * batch;
+    if (p.total_tiles <= 0) return hipSuccess;
+    long long blocks = (long long)cu_count * per_cu;
+    if (blocks > p.total_tiles) blocks = p.total_tiles;
+    const dim3 g((unsigned)blocks), b(C::W * 64);
+    if (p.out_kind == 0 && p.squeezing == 1) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, true, false, true>), g, b, 0, stream, p);
+    else if (p.out_kind == 0) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, false, false, true>), g, b, 0, stream, p);
+    else if (p.out_kind == 3) hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, true, true, false, true, true>), g, b, 0, stream, p);
+    else hipLaunchKernelGGL((stft_fused_kernel<T, LOGN, false, true, false, false, true>), g, b, 0, stream, p);
+    return hipGetLastError();
+  }
   // small jobs (a few waves of blocks, e.g. one to four 2^20-sample signals): ONE launch of the edge-capable kernel
   // over all tiles beats two launches -- the second launch costs more than the validity logic of the first
   const long long blocks_one_wave = (long long)cu_count * (hiocc == 2 ? 2 : (hiocc == 1 ? 1 : per_cu));

@@ -8,9 +8,64 @@
 //                          (stft.rs:47-85, ssq_stft.rs:191-252)
 //   reassign_cols_kernel : one thread per time column, rows ascending -- the reference's own
 //                          accumulation order, no atomics (ssq_stft.rs:276-301)
+#include "fft_generic.h"
 #include "stft_kernels.h"
 
 namespace ssq {
+
+// ---- FFT path for long / odd n_fft: pack -> batched FFT of any length -> unpack ----
+template <typename T>
+__global__ void frames_pack_kernel(StftDev<T> p, long long sig, int n_fft, GenericTabs tabs, double alpha,
+                                   cpx<T>* __restrict__ Z) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;     // sample inside the frame
+  const int f = blockIdx.y;                                // frame
+  if (j >= n_fft) return;
+  const T* xs = sig_base(p, sig);
+  const double xv = (double)load_padded(xs, (long long)f * p.hop - p.pad_left + j, p.n_signal, p.padtype);
+  Z[(long long)f * n_fft + j] = {(T)(xv * tabs.g[j]), (T)(xv * tabs.gd[j] * alpha)};
+}
+
+// Z[frame][k] -> Sx[k][frame] = (Z[k] + conj Z[n-k])/2, dSx[k][frame] = (Z[k] - conj Z[n-k])/(2i) / alpha, through a
+// 32x32 LDS tile so that both the reads (along k) and the writes (along frame) are contiguous
+template <typename T>
+__global__ void frames_unpack_kernel(const cpx<T>* __restrict__ Z, int n_fft, int n_frames, int n_freqs, T inv_alpha,
+                                     cpx<T>* __restrict__ Sx, cpx<T>* __restrict__ dSx) {
+  __shared__ cpx<T> ts[32][33], td[32][33];
+  const int k0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int f = f0 + r, k = k0 + threadIdx.x;
+    cpx<T> s = {(T)0, (T)0}, d = {(T)0, (T)0};
+    if (f < n_frames && k < n_freqs) {
+      const cpx<T> zk = Z[(long long)f * n_fft + k];
+      const cpx<T> zn = Z[(long long)f * n_fft + (k == 0 ? 0 : n_fft - k)];
+      s = {(zk.x + zn.x) * (T)0.5, (zk.y - zn.y) * (T)0.5};
+      d = {(zk.y + zn.y) * (T)0.5 * inv_alpha, (zn.x - zk.x) * (T)0.5 * inv_alpha};
+    }
+    ts[r][threadIdx.x] = s;
+    td[r][threadIdx.x] = d;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    const int k = k0 + r, f = f0 + threadIdx.x;
+    if (k < n_freqs && f < n_frames) {
+      Sx[(long long)k * n_frames + f] = ts[threadIdx.x][r];
+      if (dSx) dSx[(long long)k * n_frames + f] = td[threadIdx.x][r];
+    }
+  }
+}
+
+template <typename T>
+hipError_t launch_fft_frames(const StftDev<T>& p, long long sig, int n_fft, const GenericTabs& tabs, double alpha,
+                             cpx<T>* Z, cpx<T>* work, cpx<T>* Sx, cpx<T>* dSx, hipStream_t stream) {
+  if (p.n_frames > 65535 * 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(frames_pack_kernel<T>, dim3((n_fft + 255) / 256, p.n_frames), dim3(256), 0, stream, p, sig, n_fft, tabs,
+                     dSx ? alpha : 0.0, Z);
+  hipError_t e = fft_any_batched<T>(Z, work, n_fft, p.n_frames, -1, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(frames_unpack_kernel<T>, dim3((p.n_freqs + 31) / 32, (p.n_frames + 31) / 32), dim3(32, 8), 0, stream, Z,
+                     n_fft, p.n_frames, p.n_freqs, (T)(1.0 / alpha), Sx, dSx);
+  return hipGetLastError();
+}
 
 template <typename T>
 __global__ void dft_frames_kernel(StftDev<T> p, int n_fft, GenericTabs tabs, cpx<T>* __restrict__ Sx,
@@ -95,6 +150,10 @@ template hipError_t launch_dft_frames<float>(const StftDev<float>&, long long, i
                                              cpx<float>*, hipStream_t);
 template hipError_t launch_dft_frames<double>(const StftDev<double>&, long long, int, const GenericTabs&, cpx<double>*,
                                               cpx<double>*, hipStream_t);
+template hipError_t launch_fft_frames<float>(const StftDev<float>&, long long, int, const GenericTabs&, double, cpx<float>*,
+                                             cpx<float>*, cpx<float>*, cpx<float>*, hipStream_t);
+template hipError_t launch_fft_frames<double>(const StftDev<double>&, long long, int, const GenericTabs&, double,
+                                              cpx<double>*, cpx<double>*, cpx<double>*, cpx<double>*, hipStream_t);
 template hipError_t launch_reassign_cols<float>(const StftDev<float>&, const cpx<float>*, const cpx<float>*,
                                                 long long, hipStream_t);
 template hipError_t launch_reassign_cols<double>(const StftDev<double>&, const cpx<double>*,

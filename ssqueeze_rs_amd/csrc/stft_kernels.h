@@ -40,6 +40,13 @@ struct StftDev {
   float keep_big, keep_bias;   // fp32 TX kernel: keep-mask of |Sx|^2 >= gamma^2 as clamp(den*keep_big + keep_bias)
   int ablate;              // timing experiments only (env SSQ_ABLATE): bit mask of stages to skip; 0 in production
   T leb_unit;              // 1/n_freqs weight of "lebesgue" (ssq_stft.rs:294), without the dw factor
+  // Bluestein mode of the fused kernel (n_fft not a power of two: rustfft plans any length, stft.rs:43-44): the frame
+  // of n_eff samples is transformed through two FFTs of the kernel's own length m = 2^LOGN >= 2*n_eff - 1.
+  // win2 then holds (window * chirp) zero-padded to m, blue_b the spectrum of the chirp filter (times 1/m) and
+  // blue_post the output chirp exp(-i*pi*k^2/n_eff), k < n_eff.
+  int n_eff;               // n_fft actually transformed (== 2^LOGN outside Bluestein mode)
+  const cpx<T>* blue_b;
+  const cpx<T>* blue_post;
 };
 
 template <typename T>
@@ -68,6 +75,13 @@ struct GenericTabs {
 template <typename T>
 hipError_t launch_dft_frames(const StftDev<T>& p, long long batch, int n_fft, const GenericTabs& tabs,
                              cpx<T>* Sx, cpx<T>* dSx /*nullable*/, hipStream_t stream);
+// any-n_fft path WITHOUT the O(n_fft) sums per bin (n_fft beyond the fused kernels: > 2048 not a power of two, > 4096):
+// frames packed as z = x*g + i*x*g'*fs*alpha into [n_frames][n_fft] rows, a batched device FFT of any length
+// (fft_generic.h: Stockham passes, Bluestein for non-powers of two), unpacked into Sx / dSx [n_freqs][n_frames].
+// One signal per call; `Z` holds n_frames*n_fft elements, `work` fft_work_elems(n_fft, n_frames).
+template <typename T>
+hipError_t launch_fft_frames(const StftDev<T>& p, long long sig, int n_fft, const GenericTabs& tabs, double alpha,
+                             cpx<T>* Z, cpx<T>* work, cpx<T>* Sx, cpx<T>* dSx /*nullable*/, hipStream_t stream);
 // Sx,dSx -> out (Tx or WK), thread per time column, rows ascending (reference order, no atomics)
 template <typename T>
 hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx<T>* dSx,

@@ -286,3 +286,77 @@ def test_error_behaviour_matches_reference():
     Tx, f = _rs.ssq_stft(x[:300], np.hanning(300))
     assert Tx.shape == (151, 300)
     assert _rs.hello_from_bin() == "Hello from ssqueeze!"
+
+
+# ------------------------------------------------------- any-length n_fft: Bluestein inside the fused kernel ----
+@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (999, 100), (1001, 333), (100, 25), (24, 6), (33, 8), (600, 150),
+                                       (1025, 256), (2047, 512), (1536, 384)])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 6e-6)])
+def test_stft_bluestein_lengths(n_fft, hop, dtype, tol):
+    """rustfft plans any length (stft.rs:43-44, ssq_stft.rs:198-199); 24 <= n_fft <= 2048 that are not powers of two
+    run Bluestein's chirp-z through two power-of-two transforms of the fused kernel (no O(n^2) direct sums)."""
+    import ctypes as C
+    from ssqueeze_rs_amd import _lib
+    x = _sig(5 * n_fft + 123, 21, dtype)
+    win = np.hanning(n_fft) + 0.07
+    lib = _lib.load()
+    plan = C.c_void_p()
+    _lib.check(lib.ssq_stft_plan_create(C.byref(plan), _lib.SSQ_F32 if dtype == np.float32 else _lib.SSQ_F64, x.shape[0],
+                                        win.ctypes.data_as(C.c_void_p), n_fft, hop, 1.0, 0, 0, -1.0, 0))
+    assert lib.ssq_stft_plan_is_fused(plan) == 1                       # not the direct-sum kernels
+    lib.ssq_stft_plan_destroy(plan)
+    for pad in ("reflect", "zero"):
+        Sx, f = _rs.stft(x, n_fft, hop, win, pad)
+        Sx_o, f_o = o.stft(x.astype(np.float64), n_fft, hop, win, pad)
+        assert Sx.shape == Sx_o.shape == (n_fft // 2 + 1, (x.shape[0] - 1) // hop + 1)
+        assert np.array_equal(f, f_o)
+        assert _relerr(Sx, Sx_o) <= tol, (n_fft, pad)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (333, 83), (48, 12)])
+def test_ssq_stft_bluestein(n_fft, hop):
+    x = _sig(6000 + 3 * n_fft, 22)
+    _check_ssq_f64(x, np.hanning(n_fft), n_fft, hop, 2.0, "reflect", "sum")
+    _check_ssq_f64(x, np.hanning(n_fft), n_fft, hop, 1.0, "zero", "lebesgue")
+    _check_ssq_f32(x.astype(np.float32), np.hanning(n_fft), n_fft, hop, 1.0)
+    xb = np.stack([_sig(4000, 30 + b, np.float32) for b in range(3)])      # NaN beyond a frame must not leak into it
+    Tb, _ = _rs.ssq_stft(xb, np.hanning(n_fft), n_fft=n_fft, hop_len=hop)
+    for b in range(3):
+        assert np.array_equal(Tb[b], _rs.ssq_stft(xb[b], np.hanning(n_fft), n_fft=n_fft, hop_len=hop)[0])
+
+
+def test_bluestein_reads_only_the_frame():
+    """The kernel's transform is longer than the frame; samples beyond the frame's n_fft (here a NaN right behind a
+    short signal's last frame position cannot exist, so put NaNs INSIDE and check they stay local)."""
+    n_fft, hop = 1000, 250
+    x = _sig(8000, 23)
+    x[4000] = np.nan
+    Sx, _ = _rs.stft(x, n_fft, hop, np.hanning(n_fft), "reflect")
+    bad = np.isnan(Sx).any(axis=0)
+    frames = np.arange(Sx.shape[1])
+    start = frames * hop - (n_fft - 1) // 2
+    touches = (start <= 4000) & (4000 < start + n_fft)
+    assert np.array_equal(bad, touches)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(8192, 2048), (3000, 750), (5000, 1250), (16384, 4096), (4097, 1000)])
+def test_stft_long_lengths_through_the_batched_device_fft(n_fft, hop):
+    """n_fft beyond the fused kernels (> 4096, or > 2048 and not a power of two): pack -> batched any-length FFT
+    (Stockham passes / Bluestein) -> unpack, instead of O(n_fft) sums per bin."""
+    x = _sig(3 * n_fft + 1001, 24)
+    win = np.hanning(n_fft) + 0.03
+    Sx, f = _rs.stft(x, n_fft, hop, win, "reflect")
+    Sx_o, f_o = o.stft(x, n_fft, hop, win, "reflect")
+    assert np.array_equal(f, f_o) and _relerr(Sx, Sx_o) <= 1e-11
+    S32, _ = _rs.stft(x.astype(np.float32), n_fft, hop, win, "zero")
+    S32_o, _ = o.stft(x.astype(np.float32).astype(np.float64), n_fft, hop, win, "zero")
+    assert _relerr(S32, S32_o) <= 2e-5
+
+
+def test_ssq_stft_long_length():
+    x = _sig(20000, 25)
+    _check_ssq_f64(x, np.hanning(3000), 3000, 750, 1.0, "reflect", "sum")
+    xb = np.stack([_sig(20000, 40 + b) for b in range(2)])
+    Tb, _ = _rs.ssq_stft(xb, np.hanning(8192), n_fft=8192, hop_len=2048)
+    for b in range(2):
+        assert np.array_equal(Tb[b], _rs.ssq_stft(xb[b], np.hanning(8192), n_fft=8192, hop_len=2048)[0])
