@@ -24,7 +24,8 @@ struct ssq_cwt_plan {
   int wavelet = 0, padtype = 0, na = 0;
   double dt = 1.0;
   std::vector<double> scales;
-  void* d_psih = nullptr;      // [na][P/2+1] T
+  void* d_psih = nullptr;      // wavelet table: scale s at psi_off[s], band[s] entries of T (zero beyond: not stored)
+  long long* d_psi_off = nullptr;
   void* d_tw1 = nullptr;       // W_{P1}^i
   void* d_tw2 = nullptr;       // W_{P2}^i
   void* d_twz = nullptr;       // W_Q^i at [Q, 2Q) for Q = 16 .. 2048 (mode Z)
@@ -136,10 +137,20 @@ int build_tables(ssq_cwt_plan* pl) {
     SSQ_HIP(hipMemcpy(pl->d_scale_l2, s2.data(), sizeof(T) * pl->na, hipMemcpyHostToDevice));
     SSQ_HIP(hipMemcpy(pl->d_scales, pl->scales.data(), sizeof(double) * pl->na, hipMemcpyHostToDevice));
   }
-  const long long half = pl->P / 2;
-  SSQ_HIP(hipMalloc(&pl->d_psih, sizeof(T) * (size_t)((half + 1) * (pl->na > 0 ? pl->na : 1))));
+  std::vector<long long> off((size_t)(pl->na > 0 ? pl->na : 1), 0);
+  long long total = 0;
+  int max_band = 1;
+  for (int i = 0; i < pl->na; ++i) {
+    off[(size_t)i] = total;
+    total += pl->band[(size_t)i];
+    if (pl->band[(size_t)i] > max_band) max_band = pl->band[(size_t)i];
+  }
+  SSQ_HIP(hipMalloc(&pl->d_psih, sizeof(T) * (size_t)(total > 0 ? total : 1)));
+  SSQ_HIP(hipMalloc((void**)&pl->d_psi_off, sizeof(long long) * off.size()));
+  SSQ_HIP(hipMemcpy(pl->d_psi_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
   if (pl->na > 0) {
-    SSQ_HIP(launch_wavelet_table<T>((T*)pl->d_psih, pl->d_scales, pl->na, pl->P, pl->wavelet, nullptr));
+    SSQ_HIP(launch_wavelet_table<T>((T*)pl->d_psih, pl->d_psi_off, pl->d_band, max_band, pl->d_scales, pl->na, pl->P,
+                                    pl->wavelet, nullptr));
     SSQ_HIP(hipDeviceSynchronize());
   }
   return 0;
@@ -173,6 +184,7 @@ CwtDev<T> base_dev(const ssq_cwt_plan* pl, char* ws) {
   p.xh = (cpx<T>*)(ws + L.xh);
   p.ybuf = (cpx<T>*)(ws + L.ybuf);
   p.psih = (const T*)pl->d_psih;
+  p.psi_off = pl->d_psi_off;
   p.tw_hi = (const cpx<T>*)pl->d_twhi;
   p.tw_lo = (const cpx<T>*)pl->d_twlo;
   p.band = pl->d_band;
@@ -492,6 +504,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
 int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   if (!pl) return 0;
   hipFree(pl->d_psih);
+  hipFree(pl->d_psi_off);
   hipFree(pl->d_tw1);
   hipFree(pl->d_tw2);
   hipFree(pl->d_twz);

@@ -21,7 +21,8 @@ struct CwtDev {
   const T* x;            // [n_signal] one real signal
   cpx<T>* xh;            // [P] FFT of the padded signal             (cwt.rs:147-162)
   cpx<T>* ybuf;          // [transforms in chunk][P] step-A output
-  const T* psih;         // [na][P/2+1] wavelet table                 (cwt.rs:492-547)
+  const T* psih;         // wavelet table, scale s at psi_off[s], band[s] entries (zero beyond)   (cwt.rs:492-547)
+  const long long* psi_off;
   const cpx<T>* tw_m;    // W_M^i for the transform length of this launch
   const cpx<T>* tw_hi;   // W_P^(i << 12)
   const cpx<T>* tw_lo;   // W_P^i, i < 4096
@@ -50,10 +51,11 @@ hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream);
 template <typename T>
 int cwt_tile_rows(int logm);
 
-// wavelet table psih[s][k] = psi_hat(scale_s * 2*pi*k/P), k in [0, P/2]   (cwt.rs:492-547)
+// wavelet table psih[off[s] + k] = psi_hat(scale_s * 2*pi*k/P), k in [0, band[s])   (cwt.rs:492-547): only the span
+// where the value is not exactly zero in T is stored (1.07 GB -> 0.2 GB at C4)
 template <typename T>
-hipError_t launch_wavelet_table(T* psih, const double* d_scales, int na, long long P, int wavelet,
-                                hipStream_t stream);
+hipError_t launch_wavelet_table(T* psih, const long long* d_off, const int* d_band, int max_band, const double* d_scales,
+                                int na, long long P, int wavelet, hipStream_t stream);
 
 // any-P fallback for tiny signals (P < 64): direct sums
 template <typename T>

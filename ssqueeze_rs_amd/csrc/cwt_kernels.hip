@@ -82,9 +82,10 @@ __device__ __forceinline__ cpx<T> load_spectrum(const CwtDev<T>& p, int tr, long
   const long long nn = n > half ? half : n;
   const int s = p.scale0 + tr / p.n_kinds;
   const int kind = tr % p.n_kinds;
-  T psi = p.psih[(long long)s * (half + 1) + nn];
+  const long long bs = p.band[s];                       // psih_s is exactly zero from here on: not stored
+  T psi = p.psih[p.psi_off[s] + (nn < bs ? nn : bs - 1)];
   const cpx<T> xv = p.xh[nn];
-  if (n > half) psi = (T)0;                             // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536)
+  if (n > half || nn >= bs) psi = (T)0;                 // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536)
   cpx<T> v = {xv.x * psi, xv.y * psi};                  // cwt.rs:238-240
   if (kind == 1) {                                      // * Complex(0, xi/dt)  cwt.rs:205-208
     const T xi = (T)n * p.xi_step;
@@ -376,12 +377,11 @@ hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream) {
 // ------------------------------------------------------------- wavelet table ----
 // cwt.rs:492-547; evaluated in fp64 for both dtypes, rounded once to T.
 template <typename T>
-__global__ void wavelet_table_kernel(T* __restrict__ psih, const double* __restrict__ scales, int na,
-                                     long long P, int wavelet) {
-  const long long half = P >> 1;
+__global__ void wavelet_table_kernel(T* __restrict__ psih, const long long* __restrict__ off, const int* __restrict__ band,
+                                     const double* __restrict__ scales, int na, long long P, int wavelet) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
-  if (k > half || s >= na) return;
+  if (s >= na || k >= band[s]) return;
   const double h = 1.0 * (2.0 * 3.14159265358979323846) / (double)P;   // base.rs:20
   const double xi = (double)k * h;
   const double w = scales[s] * xi;
@@ -397,15 +397,14 @@ __global__ void wavelet_table_kernel(T* __restrict__ psih, const double* __restr
   } else {                                              // "gmw" | _  cwt.rs:522-542
     if (w > 0.0) v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
   }
-  psih[(long long)s * (half + 1) + k] = (T)v;
+  psih[off[s] + k] = (T)v;
 }
 
 template <typename T>
-hipError_t launch_wavelet_table(T* psih, const double* d_scales, int na, long long P, int wavelet,
-                                hipStream_t stream) {
-  const long long half = P >> 1;
-  dim3 grid((unsigned)((half + 1 + 255) / 256), (unsigned)na, 1);
-  hipLaunchKernelGGL(wavelet_table_kernel<T>, grid, dim3(256), 0, stream, psih, d_scales, na, P, wavelet);
+hipError_t launch_wavelet_table(T* psih, const long long* d_off, const int* d_band, int max_band, const double* d_scales,
+                                int na, long long P, int wavelet, hipStream_t stream) {
+  dim3 grid((unsigned)((max_band + 255) / 256), (unsigned)na, 1);
+  hipLaunchKernelGGL(wavelet_table_kernel<T>, grid, dim3(256), 0, stream, psih, d_off, d_band, d_scales, na, P, wavelet);
   return hipGetLastError();
 }
 
@@ -849,7 +848,8 @@ int cwt_tile_rows(int logm) {
 #define SSQ_INST(T)                                                                                   \
   template int cwt_tile_rows<T>(int);                                                                 \
   template hipError_t launch_cwt_tile<T>(int, const CwtDev<T>&, hipStream_t);                         \
-  template hipError_t launch_wavelet_table<T>(T*, const double*, int, long long, int, hipStream_t);   \
+  template hipError_t launch_wavelet_table<T>(T*, const long long*, const int*, int, const double*, int, long long, int, \
+                                              hipStream_t);                                          \
   template hipError_t launch_cwt_naive_fwd<T>(const CwtDev<T>&, hipStream_t);                         \
   template hipError_t launch_cwt_naive_inv<T>(const CwtDev<T>&, int, hipStream_t);                    \
   template hipError_t launch_cwt_reassign<T>(const CwtSsqDev<T>&, hipStream_t, bool);                 \

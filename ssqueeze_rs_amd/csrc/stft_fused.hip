@@ -691,6 +691,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_XHALF
 #define SSQ_XHALF 1                // 1: exchange 1 of the 16-wave kernel by register halves (full-width LDS stores)
 #endif
+#ifndef SSQ_PRIO
+#define SSQ_PRIO 0                 // s_setprio experiments: bit 0 = raise around the scatter, bit 1 = raise in the read-out
+#endif
 #ifndef SSQ_LATE_PREFETCH
 #define SSQ_LATE_PREFETCH 1        // 1: issue the next tile's sample loads after exchange 1 (keeps the kernel out of scratch)
 #endif
@@ -1053,6 +1056,9 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       column_scale<T, H::FRAC, H::EMIN>(tot, p.dw, scale, inv_scale);
       if (t == 0 && valid) col_scale[fl] = inv_scale;
       SSQ_STAMP(5);
+#if SSQ_PRIO & 1
+      __builtin_amdgcn_s_setprio(1);               // the short LDS-bound tail of a frame goes first
+#endif
       // fixed-point contributions; scatter one 64-bit add per bin into the (re, im) cell: the cell holds the signed
       // integer IM * 2^32 + RE (|RE| < 2^31), so a borrow of a negative RE into the high word is undone exactly at
       // the read-out (IM = high - (RE >> 31)) whatever the order of the adds
@@ -1113,13 +1119,22 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       }
       }
     }
+#if SSQ_PRIO & 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef SSQ_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // charge the atomics' drain to their own phase
 #endif
     SSQ_STAMP(6);
     __syncthreads();
     SSQ_STAMP(7);
+#if SSQ_PRIO & 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
     read_out(sig, frame0);
+#if SSQ_PRIO & 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     SSQ_STAMP(8);
     __syncthreads();
     SSQ_STAMP(9);
