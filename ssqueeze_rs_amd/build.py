@@ -78,6 +78,7 @@ if __name__ == "__main__":
         print(build_lib(extra_flags=("-DSSQ_ABLATE_HOOKS",), suffix="abl"))
     elif "--variant" in sys.argv:   # python -m ssqueeze_rs_amd.build --variant NAME -DFOO=1 ...  -> libssq_hip_NAME.so
         name = sys.argv[sys.argv.index("--variant") + 1]
-        print(build_lib(extra_flags=tuple(a for a in sys.argv if a.startswith("-D")), suffix=name))
+        idx = sys.argv.index("--variant") + 2          # everything after the name goes to hipcc (-D..., -mllvm ...)
+        print(build_lib(extra_flags=tuple(sys.argv[idx:]), suffix=name))
     else:
         print(build_lib(force="--force" in sys.argv))

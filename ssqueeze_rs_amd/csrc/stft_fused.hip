@@ -702,6 +702,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #endif
 #ifndef SSQ_T0_ROTATE
 #define SSQ_T0_ROTATE 1            // 1: lane 0's self-partner bins by a masked register rotation instead of selects
+                                   // (re-fetching them by 16 one-lane ds_bpermute instead: +17 %, profiles/r02_ab_libs4.txt)
 #endif
 #ifndef SSQ_RO_PAIR
 #define SSQ_RO_PAIR 1              // 1: read-out of the interior 16-wave kernel with 16-byte stores (two frames per thread)
