@@ -21,6 +21,7 @@ struct ssq_cwt_plan {
   long long N = 0, P = 0, n1 = 0;
   int logP = 0, log_p1 = 0, log_p2 = 0;
   bool two_step = false, naive = false;
+  bool big = false;            // P > 2^24: batched generic device FFT instead of the tile transforms
   int wavelet = 0, padtype = 0, na = 0;
   double dt = 1.0;
   std::vector<double> scales;
@@ -167,7 +168,8 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   L.xh = off;
   off += align(pl->P * csz);
   L.ybuf = off;
-  off += align(pl->two_step ? (long long)pl->chunk * 2 * pl->P * csz : 0);
+  off += align(pl->big ? 2LL * pl->chunk * 2 * pl->P * csz              // spectra of a chunk + the FFT's ping-pong half
+                       : (pl->two_step ? (long long)pl->chunk * 2 * pl->P * csz : 0));
   L.w = off;
   off += align((long long)pl->na * pl->N * csz);
   L.dw = off;                  // fused ssq path: the 16-bit row indices K live here instead of dWx
@@ -208,7 +210,9 @@ template <typename T>
 int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t st) {
   p.x = d_x;
   p.n_transforms = 1;
-  if (pl->naive) {
+  if (pl->big) {
+    SSQ_HIP(launch_cwt_big_fwd<T>(p, p.ybuf, st));
+  } else if (pl->naive) {
     SSQ_HIP(launch_cwt_naive_fwd<T>(p, st));
   } else if (pl->two_step) {
     p.tw_m = (const cpx<T>*)pl->d_tw1;
@@ -232,6 +236,15 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
   p.rpadded = rpadded ? 1 : 0;
   p.cols = rpadded ? pl->P : pl->N;
   p.out_scale = (const T*)(l1_norm ? pl->d_scale_l1 : pl->d_scale_l2);
+  if (pl->big) {
+    for (int c0 = 0; c0 < pl->na; c0 += pl->chunk) {
+      const int ns = (pl->na - c0 < pl->chunk) ? pl->na - c0 : pl->chunk;
+      p.scale0 = c0;
+      p.n_transforms = ns * p.n_kinds;
+      SSQ_HIP(launch_cwt_big_inv<T>(p, p.ybuf + (long long)pl->chunk * 2 * pl->P, st));
+    }
+    return 0;
+  }
   if (pl->naive) {
     p.scale0 = 0;
     p.n_transforms = pl->na * p.n_kinds;
@@ -450,11 +463,16 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   int lp = 0;
   while ((1LL << lp) < pl->P) ++lp;
   pl->logP = lp;
-  if (lp > 24) {
-    delete pl;
-    SSQ_FAIL("signal too long: padded length above 2^24 is not supported yet");
-  }
-  if (lp < 4) {
+  const char* force_big = std::getenv("SSQ_CWT_FORCE_BIG");     // tests: the P > 2^24 path at a small size
+  if (lp > 24 || (force_big && force_big[0] == '1' && lp >= 4)) {
+    if (lp > 30) {
+      delete pl;
+      SSQ_FAIL("signal too long: padded length above 2^30");
+    }
+    pl->big = true;                                              // cwt.rs:87 takes any N
+    pl->log_p1 = 4;                                              // (tile-kernel fields: unused on this path)
+    pl->log_p2 = 0;
+  } else if (lp < 4) {
     pl->naive = true;
     pl->log_p1 = lp;
     pl->log_p2 = 0;
@@ -478,7 +496,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   pl->band.assign((size_t)na, (int)(pl->P / 2 + 1));
   // SSQ_CWT_NOPRUNE=1 (tests): every scale through the plain two-step transform, no band-limit shortcuts
   const char* noprune = std::getenv("SSQ_CWT_NOPRUNE");
-  if (pl->two_step && !(noprune && noprune[0] == '1')) {
+  if ((pl->two_step || pl->big) && !(noprune && noprune[0] == '1')) {
     const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
     const double wmax = wavelet_support(wavelet, dtype);
     for (int64_t i = 0; i < na; ++i) {
@@ -486,7 +504,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       if (!(a > 0.0) || !std::isfinite(a)) continue;
       const double kb = wmax / (a * h) + 2.0;                        // psih_i[k] == 0 for k >= kb
       if (kb < (double)(pl->P / 2 + 1)) pl->band[(size_t)i] = (int)kb + 1;
-      if (kb > (double)kZoomMaxQ) continue;
+      if (kb > (double)kZoomMaxQ || pl->big) continue;
       int lq = 4;
       while ((double)(1LL << lq) < kb) ++lq;
       pl->zoom_logq[(size_t)i] = lq;
@@ -563,14 +581,25 @@ int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* pl, const void* d_x, int64_t batch, int 
 // ---- D2H of signal b on a second stream while signal b+1 computes -----------------------------------------------
 namespace {
 
+// the switches plan creation reads from the environment are part of the key (tests flip them between calls)
+std::string plan_env() {
+  std::string k;
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB"}) {
+    const char* e = std::getenv(v);
+    k += e ? e : "";
+    k += '|';
+  }
+  return k;
+}
 struct CwtKey {
   int dtype, wavelet, padtype;
   int64_t n_signal;
   double dt;
   std::vector<double> scales;
+  std::string env = plan_env();
   bool operator==(const CwtKey& o) const {
     return dtype == o.dtype && wavelet == o.wavelet && padtype == o.padtype && n_signal == o.n_signal && dt == o.dt &&
-           scales == o.scales;
+           scales == o.scales && env == o.env;
   }
 };
 struct CachedCwt {

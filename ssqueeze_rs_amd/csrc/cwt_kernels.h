@@ -57,6 +57,13 @@ template <typename T>
 hipError_t launch_wavelet_table(T* psih, const long long* d_off, const int* d_band, int max_band, const double* d_scales,
                                 int na, long long P, int wavelet, hipStream_t stream);
 
+// P > 2^24 (beyond the two-step tile transforms): the same pipeline through the batched any-length device FFT
+// (fft_generic.h, Stockham passes through global memory) -- functional for any length the memory holds, not tuned.
+template <typename T>
+hipError_t launch_cwt_big_fwd(const CwtDev<T>& p, cpx<T>* work, hipStream_t stream);                // p.x -> p.xh
+template <typename T>
+hipError_t launch_cwt_big_inv(const CwtDev<T>& p, cpx<T>* work, hipStream_t stream);                // p.n_transforms via p.ybuf
+
 // any-P fallback for tiny signals (P < 64): direct sums
 template <typename T>
 hipError_t launch_cwt_naive_fwd(const CwtDev<T>& p, hipStream_t stream);

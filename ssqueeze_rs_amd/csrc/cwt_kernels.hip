@@ -17,6 +17,7 @@
 // Inverse transforms run the forward FFT core on conjugated data (ifft(x) = conj(fft(conj(x)))).
 #include "cwt_kernels.h"
 #include "fft_core.h"
+#include "fft_generic.h"
 #include "stft_kernels.h"   // load_padded
 
 namespace ssq {
@@ -452,6 +453,39 @@ hipError_t launch_cwt_naive_inv(const CwtDev<T>& p, int n_transforms, hipStream_
   return hipGetLastError();
 }
 
+// ------------------------------------------------------ P > 2^24: generic FFT path ----
+template <typename T>
+__global__ void cwt_big_pad_kernel(CwtDev<T> p) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < p.P) p.xh[n] = {load_padded(p.x, n - p.n1, p.n_signal, p.padtype), (T)0};
+}
+template <typename T>
+__global__ void cwt_big_spectrum_kernel(CwtDev<T> p) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tr = blockIdx.y;
+  if (k < p.P) p.ybuf[(long long)tr * p.P + k] = load_spectrum(p, tr, k);
+}
+template <typename T>
+__global__ void cwt_big_store_kernel(CwtDev<T> p) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int tr = blockIdx.y;
+  if (n < p.P) store_time(p, time_dst(p, tr), n, p.ybuf[(long long)tr * p.P + n]);
+}
+template <typename T>
+hipError_t launch_cwt_big_fwd(const CwtDev<T>& p, cpx<T>* work, hipStream_t stream) {
+  hipLaunchKernelGGL(cwt_big_pad_kernel<T>, dim3((unsigned)((p.P + 255) / 256)), dim3(256), 0, stream, p);
+  return fft_any_batched<T>(p.xh, work, p.P, 1, -1, stream);
+}
+template <typename T>
+hipError_t launch_cwt_big_inv(const CwtDev<T>& p, cpx<T>* work, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.P + 255) / 256), (unsigned)p.n_transforms);
+  hipLaunchKernelGGL(cwt_big_spectrum_kernel<T>, grid, dim3(256), 0, stream, p);
+  const hipError_t e = fft_any_batched<T>(p.ybuf, work, p.P, p.n_transforms, +1, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cwt_big_store_kernel<T>, grid, dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------ phase transform + reassignment ----
 // ssq_cwt.rs:15-47 (phase_cwt) and :116-222 (ssqueeze).
 // Phase transform and bin of one (scale, time) element: returns the Tx row (after flipud) or -1.
@@ -851,6 +885,8 @@ int cwt_tile_rows(int logm) {
   template hipError_t launch_wavelet_table<T>(T*, const long long*, const int*, int, const double*, int, long long, int, \
                                               hipStream_t);                                          \
   template hipError_t launch_cwt_naive_fwd<T>(const CwtDev<T>&, hipStream_t);                         \
+  template hipError_t launch_cwt_big_fwd<T>(const CwtDev<T>&, cpx<T>*, hipStream_t);                  \
+  template hipError_t launch_cwt_big_inv<T>(const CwtDev<T>&, cpx<T>*, hipStream_t);                  \
   template hipError_t launch_cwt_naive_inv<T>(const CwtDev<T>&, int, hipStream_t);                    \
   template hipError_t launch_cwt_reassign<T>(const CwtSsqDev<T>&, hipStream_t, bool);                 \
   template hipError_t launch_cwt_tile_ssq<T>(int, const CwtDev<T>&, const CwtSsqDev<T>&, hipStream_t); \

@@ -219,10 +219,18 @@ __device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem
                                              T (&xv)[16], int t = 0) {
   constexpr int L = FusedCfg<T, LOGN>::L;
   if constexpr (BLUE) {
-    // only the n_eff samples of the frame are read (the table's zero padding must not meet a NaN beyond it)
+    // only the n_eff samples of the frame are read (the table's zero padding must not meet a NaN beyond it); they all
+    // sit in q < 8 (n_eff <= (m + 1)/2), and a frame that lies inside the signal needs no mirroring logic
+    const long long first = w.pos0 - t;
+    const bool inside = first >= 0 && first + p.n_eff <= p.n_signal;
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      xv[q] = (w.valid && t + L * q < p.n_eff) ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+    for (int q = 0; q < 8; ++q) {
+      const bool live = w.valid && t + L * q < p.n_eff;
+      if (inside) xv[q] = live ? w.xs[w.pos0 + L * q] : (T)0;
+      else xv[q] = live ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+    }
+#pragma unroll
+    for (int q = 8; q < 16; ++q) xv[q] = (T)0;
   } else if constexpr (!EDGE) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
@@ -428,7 +436,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       if constexpr (MULTIWAVE) __syncthreads();          // the exchange row is reused by the second transform
       fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 8; ++q) {                        // outputs k < n_eff <= m/2 only: q < 8
         const int k = t + L * q;
         const cpx<T> c = (k < p.n_eff) ? p.blue_post[k] : cpx<T>{(T)0, (T)0};
         v[0][q] = cmul(cpx<T>{v[0][q].x, -v[0][q].y}, c);
@@ -443,7 +451,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       if constexpr (BLUE) {
         frame_sync<MULTIWAVE>();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) exch[exch_phys(t + L * q)] = v[f][q];
+        for (int q = 0; q < 8; ++q) exch[exch_phys(t + L * q)] = v[f][q];   // every k < n_eff (and every partner) has q < 8
         frame_sync<MULTIWAVE>();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

@@ -281,3 +281,17 @@ def test_fused_step_b_equals_unfused(monkeypatch):
         assert clean.mean() > 0.9
         assert np.abs(T0[:, clean] - T1[:, clean]).max() <= 50 * tol * np.abs(T0).max()
         assert np.abs(T0.sum(0) - T1.sum(0)).max() <= 50 * tol * np.abs(T0).max() + np.abs(d0["Wx"][diff]).max(initial=0.0)
+
+
+def test_big_padded_length_path(monkeypatch):
+    """Padded lengths above 2^24 (the reference takes any N, cwt.rs:87) run the same pipeline through the batched generic
+    device FFT; SSQ_CWT_FORCE_BIG=1 selects that path at a testable size.  Checked against the oracle like every other
+    path, and against the tile transforms."""
+    monkeypatch.setenv("SSQ_CWT_FORCE_BIG", "1")
+    _check_ssq_cwt(_sig(12000, 5), 1e-11, wavelet="morlet", nv=4)
+    _check_ssq_cwt(_sig(5000, 6, np.float32), 1e-5, wavelet="gmw", nv=2, fs=100.0)
+    x = _sig(20000, 12)
+    W1, sc, dW1 = _rs.cwt(x, wavelet="morlet", nv=5, derivative=True, l1_norm=False, rpadded=True)
+    monkeypatch.setenv("SSQ_CWT_FORCE_BIG", "0")
+    W0, _, dW0 = _rs.cwt(x, wavelet="morlet", nv=5, derivative=True, l1_norm=False, rpadded=True)
+    assert _rel(W1, W0) <= 1e-12 and _rel(dW1, dW0) <= 1e-12
