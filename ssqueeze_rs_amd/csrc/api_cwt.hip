@@ -41,6 +41,15 @@ struct ssq_cwt_plan {
   void* d_scale_l2 = nullptr;  // [na] sqrt(a)/P
   double* d_scales = nullptr;
   int chunk = 1;               // scales per inverse-FFT chunk
+  // register-core path of the two-step scales (cwt_reg.hip): fp32, P = 2^20 or 2^21
+  bool reg = false;
+  int reg_D = 0;               // P / 2^20
+  void* d_psiT = nullptr;      // transposed wavelet table of the two-step scales
+  long long* d_psiT_off = nullptr;
+  int* d_psiT_A = nullptr;
+  void* d_tw1024 = nullptr;    // W_1024^j
+  void* d_tw20 = nullptr;      // W_{2^20}^i, i < 1024
+  int n_cus = 256;
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -59,7 +68,25 @@ struct ssq_cwt_plan {
 namespace {
 
 const long double kPI = 3.14159265358979323846264338327950288L;
-constexpr long long kZoomMaxQ = 2048;   // longest single-pass (mode Z) transform: C = 8 rows of it fit the LDS in fp32
+constexpr long long kZoomTabQ = 4096;   // twiddle table extent of the single-pass (mode Z) transforms (tile kernel: LOGM <= 12)
+// longest single-pass (mode Z) transform actually used (SSQ_CWT_ZMAXQ, a power of two <= 4096; read at plan creation)
+long long zoom_max_q() {
+  long long q = 2048;
+  if (const char* e = std::getenv("SSQ_CWT_ZMAXQ")) {
+    const long long v = std::atoll(e);
+    if (v >= 16 && v <= kZoomTabQ && (v & (v - 1)) == 0) q = v;
+  }
+  return q;
+}
+
+// SSQ_CWT_GROUP (read per call): 0 reassigns once per call (one pass over Wx / dWx from HBM) instead of group by group;
+// n > 0 sets the scales per group of the band-limited runs (default: the two-step chunk)
+int ssq_group_env(int dflt) {
+  const char* e = std::getenv("SSQ_CWT_GROUP");
+  if (!e) return dflt;
+  const int v = std::atoi(e);
+  return v < 0 ? dflt : v;
+}
 
 // Smallest w beyond which the wavelet table entry is exactly zero in T (the table is evaluated in fp64 and
 // rounded once to T: csrc/cwt_kernels.hip::wavelet_table_kernel), with margin.
@@ -109,8 +136,8 @@ int build_tables(ssq_cwt_plan* pl) {
       if (!used) continue;
       if (int rc = upload_f2(&pl->d_f2z[lq], cwt_tile_rows<T>(lq), 1LL << lq, false)) return rc;
     }
-    std::vector<cpx<T>> hz(2 * kZoomMaxQ);
-    for (long long Q = 16; Q <= kZoomMaxQ; Q *= 2)
+    std::vector<cpx<T>> hz(2 * kZoomTabQ);
+    for (long long Q = 16; Q <= kZoomTabQ; Q *= 2)
       for (long long i = 0; i < Q; ++i) {
         const long double ang = 2.0L * kPI * (long double)i / (long double)Q;
         hz[(size_t)(Q + i)] = {(T)cosl(ang), (T)(-sinl(ang))};
@@ -154,11 +181,42 @@ int build_tables(ssq_cwt_plan* pl) {
                                     pl->wavelet, nullptr));
     SSQ_HIP(hipDeviceSynchronize());
   }
+  if constexpr (sizeof(T) == 4) {
+    if (pl->reg && pl->na > 0) {
+      std::vector<int> A((size_t)pl->na, 0);
+      std::vector<long long> offT((size_t)pl->na, 0);
+      long long totT = 0;
+      int max_A = 0;
+      for (int i = 0; i < pl->na; ++i) {
+        if (pl->zoom_logq[(size_t)i] != 0) continue;             // band-limited scales keep the single-pass path
+        long long b = pl->band[(size_t)i];
+        if (b > (1LL << 20)) b = 1LL << 20;                      // D = 2: k = P/2 is added separately
+        A[(size_t)i] = (int)((b + 1023) / 1024);
+        offT[(size_t)i] = totT;
+        totT += (long long)A[(size_t)i] * 1024;
+        if (A[(size_t)i] > max_A) max_A = A[(size_t)i];
+      }
+      SSQ_HIP(hipMalloc(&pl->d_psiT, sizeof(float) * (size_t)(totT > 0 ? totT : 1)));
+      SSQ_HIP(hipMalloc((void**)&pl->d_psiT_off, sizeof(long long) * A.size()));
+      SSQ_HIP(hipMalloc((void**)&pl->d_psiT_A, sizeof(int) * A.size()));
+      SSQ_HIP(hipMemcpy(pl->d_psiT_off, offT.data(), sizeof(long long) * A.size(), hipMemcpyHostToDevice));
+      SSQ_HIP(hipMemcpy(pl->d_psiT_A, A.data(), sizeof(int) * A.size(), hipMemcpyHostToDevice));
+      SSQ_HIP(launch_cwt_reg_table((float*)pl->d_psiT, pl->d_psiT_off, pl->d_psiT_A, max_A, (const float*)pl->d_psih,
+                                   pl->d_psi_off, pl->d_band, pl->na, nullptr));
+      SSQ_HIP(hipDeviceSynchronize());
+      if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
+      if (int rc = upload_tw<float>(&pl->d_tw20, 1024, 1LL << 20, 1)) return rc;
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        pl->n_cus = prop.multiProcessorCount;
+    }
+  }
   return 0;
 }
 
 struct WsLayout {
-  long long xh = 0, ybuf = 0, w = 0, dw = 0, total = 0;
+  long long xh = 0, ybuf = 0, w = 0, dw = 0, xc = 0, total = 0;
 };
 WsLayout ws_layout(const ssq_cwt_plan* pl) {
   const long long csz = pl->dtype == SSQ_F32 ? 8 : 16;
@@ -174,6 +232,8 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   off += align((long long)pl->na * pl->N * csz);
   L.dw = off;                  // fused ssq path: the 16-bit row indices K live here instead of dWx
   off += align((long long)pl->na * pl->N * csz);     // dWx (unfused path) or the 16-bit row indices (fused path)
+  L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
+  if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
   L.total = off;
   return L;
 }
@@ -205,6 +265,43 @@ CwtDev<T> base_dev(const ssq_cwt_plan* pl, char* ws) {
   return p;
 }
 
+// parameter block of the register-core kernels from the tile kernels' one (fp32 plans with pl->reg only)
+template <typename T>
+CwtRegDev reg_dev(const ssq_cwt_plan* pl, const CwtDev<T>& p) {
+  CwtRegDev r;
+  std::memset(&r, 0, sizeof(r));
+  if constexpr (sizeof(T) == 4) {
+    r.xc = (cpx<float>*)((char*)p.xh + (ws_layout(pl).xc - ws_layout(pl).xh));
+    r.psiT = (const float*)pl->d_psiT;
+    r.psiT_off = pl->d_psiT_off;
+    r.psiT_A = pl->d_psiT_A;
+    r.tw1024 = (const cpx<float>*)pl->d_tw1024;
+    r.tw20 = (const cpx<float>*)pl->d_tw20;
+    r.ybuf = p.ybuf;
+    r.xh = p.xh;
+    r.psih = p.psih;
+    r.psi_off = p.psi_off;
+    r.band = p.band;
+    r.tw_hi = p.tw_hi;
+    r.tw_lo = p.tw_lo;
+    r.out_scale = p.out_scale;
+    r.Wx = p.Wx;
+    r.dWx = p.dWx;
+    r.n_signal = p.n_signal;
+    r.P = p.P;
+    r.n1 = p.n1;
+    r.cols = p.cols;
+    r.rpadded = p.rpadded;
+    r.D = pl->reg_D;
+    r.scale0 = p.scale0;
+    r.n_kinds = p.n_kinds;
+    r.n_transforms = p.n_transforms;
+    r.xi_step = p.xi_step;
+    if (const char* e = std::getenv("SSQ_CWT_REG_ABL")) r.abl = std::atoi(e);
+  }
+  return r;
+}
+
 // forward FFT of the padded signal  (cwt.rs:87-95)
 template <typename T>
 int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t st) {
@@ -219,6 +316,7 @@ int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t s
     SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_A, p, st));
     p.tw_m = (const cpx<T>*)pl->d_tw2;
     SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_B, p, st));
+    if (pl->reg) SSQ_HIP(launch_cwt_reg_prep(reg_dev<T>(pl, p), st));
   } else {
     p.tw_m = (const cpx<T>*)pl->d_tw1;
     SSQ_HIP(launch_cwt_tile<T>(CWT_FWD_S, p, st));
@@ -227,9 +325,14 @@ int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t s
 }
 
 // per-scale wavelet multiply + inverse FFT + normalise + unpad  (cwt.rs:228-310, :108-129)
-template <typename T>
+// `after(s0, s1)` runs behind every group of scales whose outputs are complete (the ssq path reassigns there); with
+// group > 0 the band-limited runs are cut into launches of at most `group` scales so that a group fits the cache.
+struct NoAfter {
+  int operator()(int, int) const { return 0; }
+};
+template <typename T, typename After = NoAfter>
 int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bool l1_norm, bool rpadded,
-                hipStream_t st) {
+                hipStream_t st, After after = After(), int group = 0) {
   p.Wx = Wx;
   p.dWx = dWx;
   p.n_kinds = dWx ? 2 : 1;
@@ -242,6 +345,7 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
       p.scale0 = c0;
       p.n_transforms = ns * p.n_kinds;
       SSQ_HIP(launch_cwt_big_inv<T>(p, p.ybuf + (long long)pl->chunk * 2 * pl->P, st));
+      if (int rc = after(c0, c0 + ns)) return rc;
     }
     return 0;
   }
@@ -249,14 +353,14 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
     p.scale0 = 0;
     p.n_transforms = pl->na * p.n_kinds;
     SSQ_HIP(launch_cwt_naive_inv<T>(p, p.n_transforms, st));
-    return 0;
+    return after(0, pl->na);
   }
   if (!pl->two_step) {
     p.scale0 = 0;
     p.n_transforms = pl->na * p.n_kinds;
     p.tw_m = (const cpx<T>*)pl->d_tw1;
     SSQ_HIP(launch_cwt_tile<T>(CWT_INV_S, p, st));
-    return 0;
+    return after(0, pl->na);
   }
   // runs of consecutive scales on the same path: band-limited ones (mode Z, grouped by Q) in one launch per run,
   // the others through the two-step transform in chunks whose ybuf stays inside the Infinity Cache
@@ -267,22 +371,32 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
     while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq) ++s1;
     if (lq > 0) {
       CwtDev<T> z = p;
-      z.scale0 = s0;
-      z.n_transforms = (s1 - s0) * p.n_kinds;
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
       z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
       z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
-      SSQ_HIP(launch_cwt_tile<T>(CWT_INV_Z, z, st));
+      const int step = group > 0 ? group : s1 - s0;
+      for (int c0 = s0; c0 < s1; c0 += step) {
+        const int ns = (s1 - c0 < step) ? s1 - c0 : step;
+        z.scale0 = c0;
+        z.n_transforms = ns * p.n_kinds;
+        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_Z, z, st));
+        if (int rc = after(c0, c0 + ns)) return rc;
+      }
     } else {
       for (int c0 = s0; c0 < s1; c0 += pl->chunk) {
         const int ns = (s1 - c0 < pl->chunk) ? s1 - c0 : pl->chunk;
         p.scale0 = c0;
         p.n_transforms = ns * p.n_kinds;
-        p.tw_m = (const cpx<T>*)pl->d_tw1;
-        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
-        p.tw_m = (const cpx<T>*)pl->d_tw2;
-        SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+        if (pl->reg) {
+          SSQ_HIP(launch_cwt_reg_inv(reg_dev<T>(pl, p), pl->n_cus, st));
+        } else {
+          p.tw_m = (const cpx<T>*)pl->d_tw1;
+          SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
+          p.tw_m = (const cpx<T>*)pl->d_tw2;
+          SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+        }
+        if (int rc = after(c0, c0 + ns)) return rc;
       }
     }
     s0 = s1;
@@ -405,6 +519,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     return 0;
   }
   const bool side_clear = pl->can_fuse_ssq();             // big plans: clear Tx beside the transforms here too
+  const int group = side_clear ? ssq_group_env(0) : 0;
   if (side_clear && !pl->side) {
     SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
     SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
@@ -422,12 +537,28 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
     cpx<T>* W = (cpx<T>*)(ws + L.w);
     cpx<T>* dW = (cpx<T>*)(ws + L.dw);
-    if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st)) return rc;   // ssq_cwt is always L1 (:405)
     q.Wx = W;
     q.dWx = dW;
     q.wk = d_dbg_wk ? (cpx<T>*)d_dbg_wk + b * plane : nullptr;
-    if (side_clear) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
-    SSQ_HIP(launch_cwt_reassign<T>(q, st, !side_clear));
+    if (group > 0) {
+      // reassign each group of scales right behind its transforms, while its Wx / dWx are still in the Infinity Cache
+      bool joined = false;
+      auto after = [&](int s0, int s1) -> int {
+        if (!joined) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
+        joined = true;
+        q.s_begin = s0;
+        q.s_end = s1;
+        SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
+        return 0;
+      };
+      if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, after, group)) return rc;   // always L1 (:405)
+    } else {
+      if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st)) return rc;
+      if (side_clear) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
+      q.s_begin = 0;
+      q.s_end = n;
+      SSQ_HIP(launch_cwt_reassign<T>(q, st, !side_clear));
+    }
     if (d_dbg_Wx)
       SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
                              hipMemcpyDeviceToDevice, st));
@@ -485,6 +616,12 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
     if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 0)
     pl->log_p1 = lp - pl->log_p2;
   }
+  // SSQ_CWT_REG=0 keeps the tile kernels for the two-step scales (A/B and tests)
+  {
+    const char* e = std::getenv("SSQ_CWT_REG");
+    pl->reg = dtype == SSQ_F32 && pl->two_step && (lp == 20 || lp == 21) && !(e && std::atoi(e) == 0);
+    pl->reg_D = pl->reg ? (int)(pl->P >> 20) : 0;
+  }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
   long long chunk_mb = 128;                                      // ybuf of a chunk stays inside the 256 MB Infinity Cache
   if (const char* e = std::getenv("SSQ_CWT_CHUNK_MB")) chunk_mb = std::atoll(e) > 0 ? std::atoll(e) : chunk_mb;   // tuning switch
@@ -504,7 +641,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       if (!(a > 0.0) || !std::isfinite(a)) continue;
       const double kb = wmax / (a * h) + 2.0;                        // psih_i[k] == 0 for k >= kb
       if (kb < (double)(pl->P / 2 + 1)) pl->band[(size_t)i] = (int)kb + 1;
-      if (kb > (double)kZoomMaxQ || pl->big) continue;
+      if (kb > (double)zoom_max_q() || pl->big) continue;
       int lq = 4;
       while ((double)(1LL << lq) < kb) ++lq;
       pl->zoom_logq[(size_t)i] = lq;
@@ -534,6 +671,11 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_scale_l1);
   hipFree(pl->d_scale_l2);
   hipFree(pl->d_scales);
+  hipFree(pl->d_psiT);
+  hipFree(pl->d_psiT_off);
+  hipFree(pl->d_psiT_A);
+  hipFree(pl->d_tw1024);
+  hipFree(pl->d_tw20);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -584,7 +726,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

@@ -78,6 +78,7 @@ struct CwtSsqDev {
   cpx<T>* wk;            // [na][N] (w, k or -1) or NULL
   long long N;
   int na;
+  int s_begin, s_end;    // scales this launch reassigns (launch_cwt_reassign; the whole call: 0, na)
   int is_log;            // ssq_cwt.rs:135-139
   int squeezing;
   int flipud;
@@ -99,5 +100,33 @@ hipError_t launch_cwt_tile_ssq(int mode, const CwtDev<T>& p, const CwtSsqDev<T>&
 // Tx must be zero on entry (the caller clears it on a side stream while the transforms run).
 template <typename T>
 hipError_t launch_cwt_reassign_k(const CwtSsqDev<T>& p, const short* K, hipStream_t stream);
+
+// ---- cwt_reg.hip: fp32 inverse transforms of P = 2^20 / 2^21 on the per-wave register FFT core ----
+struct CwtRegDev {
+  cpx<float>* xc;              // [D][1024 b][1024 a]  conj(X[k] e^{+2 pi i k d/P}), k = 1024 a + b
+  const float* psiT;           // transposed wavelet table: scale s at psiT_off[s], [1024 b][A_s]
+  const long long* psiT_off;
+  const int* psiT_A;           // a-extent of scale s = ceil(min(band_s, 2^20) / 1024)
+  const cpx<float>* tw1024;    // W_1024^j
+  const cpx<float>* tw20;      // W_{2^20}^i, i < 1024
+  cpx<float>* ybuf;            // [transform][d][b][n_a]
+  const cpx<float>* xh;        // natural-order spectrum (prep input; the k = P/2 term)
+  const float* psih;           // natural-order table (the k = P/2 term)
+  const long long* psi_off;
+  const int* band;
+  const cpx<float>* tw_hi;     // W_P^(i << 12)
+  const cpx<float>* tw_lo;     // W_P^i, i < 4096
+  const float* out_scale;
+  cpx<float>* Wx;
+  cpx<float>* dWx;
+  long long n_signal, P, n1, cols;
+  int rpadded, D, scale0, n_kinds, n_transforms;
+  float xi_step;
+  int abl;                     // ablation bits (SSQ_CWT_REG_ABL, experiments only; results wrong by construction)
+};
+hipError_t launch_cwt_reg_prep(const CwtRegDev& p, hipStream_t stream);                       // xh -> xc
+hipError_t launch_cwt_reg_table(float* psiT, const long long* d_offT, const int* d_A, int max_A, const float* psih,
+                                const long long* d_off, const int* d_band, int na, hipStream_t stream);
+hipError_t launch_cwt_reg_inv(const CwtRegDev& p, int n_cus, hipStream_t stream);             // R1 + R2 of p.n_transforms
 
 }  // namespace ssq

@@ -796,27 +796,29 @@ hipError_t launch_cwt_reassign_k(const CwtSsqDev<T>& p, const short* K, hipStrea
 // read-modify-writing a zero-filled Tx; runs of scales that land in the same row are summed in registers first (the
 // reference adds them to the row one by one: same sum up to the order of two roundings).  (An LDS-resident Tx tile [na][64 columns] with the rows split
 // over 4 waves was measured 2.5x slower on C4: 128 KB of LDS leaves 4 waves per CU, too few loads in flight.)
-template <typename T>
+// Scales [p.s_begin, p.s_end) only: the host may reassign group by group right behind the transforms that produced the
+// group, while its Wx / dWx are still in the Infinity Cache (api_cwt.hip); rows are then read-modify-written once per
+// group instead of once per call.  UN = scales whose Wx / dWx loads are in flight together.
+template <typename T, int UN>
 __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.N) return;
   const cpx<T>* __restrict__ Wxp = p.Wx + j;
   const cpx<T>* __restrict__ dWxp = p.dWx + j;
-  constexpr int UN = 8;                                  // scales whose Wx / dWx loads are in flight together
   int k_cur = -1;
   cpx<T> acc = {(T)0, (T)0};
-  for (int i0 = 0; i0 < p.na; i0 += UN) {
+  for (int i0 = p.s_begin; i0 < p.s_end; i0 += UN) {
     cpx<T> Wb[UN], dWb[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
+      const int ii = (i0 + u < p.s_end) ? i0 + u : p.s_end - 1;
       Wb[u] = Wxp[(long long)ii * p.N];
       dWb[u] = dWxp[(long long)ii * p.N];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int i = i0 + u;
-      if (i >= p.na) break;
+      if (i >= p.s_end) break;
       const long long o = (long long)i * p.N + j;
       const cpx<T> Wv = Wb[u];
       T w;
@@ -859,7 +861,10 @@ hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream, bool c
     const hipError_t e = hipMemsetAsync(p.Tx, 0, (size_t)p.na * (size_t)p.N * sizeof(cpx<T>), stream);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(cwt_reassign_kernel<T>, dim3((unsigned)((p.N + 63) / 64)), dim3(64), 0, stream, p);
+  if (p.s_end <= p.s_begin) return hipSuccess;
+  const dim3 grid((unsigned)((p.N + 63) / 64));
+  if (p.s_end - p.s_begin <= 4) hipLaunchKernelGGL((cwt_reassign_kernel<T, 4>), grid, dim3(64), 0, stream, p);
+  else hipLaunchKernelGGL((cwt_reassign_kernel<T, 8>), grid, dim3(64), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -295,3 +295,27 @@ def test_big_padded_length_path(monkeypatch):
     monkeypatch.setenv("SSQ_CWT_FORCE_BIG", "0")
     W0, _, dW0 = _rs.cwt(x, wavelet="morlet", nv=5, derivative=True, l1_norm=False, rpadded=True)
     assert _rel(W1, W0) <= 1e-12 and _rel(dW1, dW0) <= 1e-12
+
+
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+@pytest.mark.parametrize("N", [600_000, 1 << 20])
+def test_cwt_register_core_path(wavelet, N, monkeypatch):
+    """fp32 plans with P = 2^20 (N = 600 000: one residue) and P = 2^21 (N = 2^20, C4's geometry: two residues and the
+    k = P/2 term) run their two-step scales on the per-wave register FFT core (csrc/cwt_reg.hip).  Per scale against the
+    oracle, and against the tile kernels (SSQ_CWT_REG=0) to rounding; the scales sit on both sides of the band switch
+    (full band with a live k = P/2 term, partly dead rows, single-pass scales)."""
+    x = _sig(N, 5, np.float32)
+    scales = np.array([1.0, 1.7, 3.1, 6.0, 19.0, 77.0, 150.0, 900.0, 20000.0])
+    Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
+    Wp, _, dWp = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=True, derivative=True, rpadded=True)
+    monkeypatch.setenv("SSQ_CWT_REG", "0")
+    Wx0, sc0, dWx0 = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
+    Wp0, _, dWp0 = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=True, derivative=True, rpadded=True)
+    assert np.array_equal(sc, sc0) and Wp.shape == Wp0.shape
+    for a, b in ((Wx, Wx0), (dWx, dWx0), (Wp, Wp0), (dWp, dWp0)):
+        row_max = np.abs(b).max(axis=1, keepdims=True)
+        assert (np.abs(a - b) <= 4e-6 * row_max).all()
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
+    for i in range(len(scales)):
+        assert np.abs(Wx[i] - Wx_o[i]).max() <= 2e-5 * np.abs(Wx_o[i]).max(), i
+        assert np.abs(dWx[i] - dWx_o[i]).max() <= 2e-5 * np.abs(dWx_o[i]).max(), i
