@@ -297,7 +297,6 @@ CwtRegDev reg_dev(const ssq_cwt_plan* pl, const CwtDev<T>& p) {
     r.n_kinds = p.n_kinds;
     r.n_transforms = p.n_transforms;
     r.xi_step = p.xi_step;
-    if (const char* e = std::getenv("SSQ_CWT_REG_ABL")) r.abl = std::atoi(e);
   }
   return r;
 }

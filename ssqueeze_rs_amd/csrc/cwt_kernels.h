@@ -122,7 +122,6 @@ struct CwtRegDev {
   long long n_signal, P, n1, cols;
   int rpadded, D, scale0, n_kinds, n_transforms;
   float xi_step;
-  int abl;                     // ablation bits (SSQ_CWT_REG_ABL, experiments only; results wrong by construction)
 };
 hipError_t launch_cwt_reg_prep(const CwtRegDev& p, hipStream_t stream);                       // xh -> xc
 hipError_t launch_cwt_reg_table(float* psiT, const long long* d_offT, const int* d_A, int max_A, const float* psih,

@@ -19,6 +19,19 @@
 
 namespace ssq {
 
+// ablation bits of a diagnostic build (python -m ssqueeze_rs_amd.build --variant X -DSSQ_REG_ABL=n; results wrong by
+// construction): R1 1 no loads, 2 no stores, 4 no FFT; R2 8 no loads, 16 no stores, 32 no FFT.  profiles/r02_abl_cwt_reg.txt
+#ifndef SSQ_REG_ABL
+#define SSQ_REG_ABL 0
+#endif
+#define REG_ABL(bit) ((SSQ_REG_ABL & (bit)) != 0)
+#ifndef SSQ_R2_XCDPAIR
+#define SSQ_R2_XCDPAIR 1
+#endif
+#ifndef SSQ_R2_EARLY
+#define SSQ_R2_EARLY 0      // 1: issue the next tile's 16 loads at the top of the tile (32 more registers across the FFT): +1.7 % on C4
+#endif
+
 namespace {
 
 constexpr int kRegThreads = 1024;       // 16 waves, one block per CU
@@ -58,7 +71,9 @@ __global__ void cwt_reg_table_kernel(float* __restrict__ psiT, const long long* 
 }
 
 // ---------------------------------------------------------------------------------------------------- step R1 ----
-// item = (transform tr, residue d, row b): one wave each, persistent over items g, g + G, ...
+// item = (transform tr, residue d, row b): one wave each.  A wave takes the row groups (scale, b) g, g + G, ... and
+// runs the residues and kinds of a group back to back: they share the wavelet row and (per residue) the spectrum row,
+// so three of four loads hit the cache.
 __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r1_kernel(CwtRegDev p) {
   __shared__ __attribute__((aligned(16))) cpx<float> exch_all[kRegWaves * kWave1024ExchElems];
   __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
@@ -77,26 +92,30 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r1_kernel(CwtRegDev p)
 
   const int logD = p.D >> 1;                                     // D = 1 or 2
   const int kshift = p.n_kinds - 1;                              // n_kinds = 1 or 2
-  const int items = (p.n_transforms << logD) << 10;
+  const int lsub = logD + kshift;                                // sub-items (d, kind) of a row group
+  const int groups = (p.n_transforms >> kshift) << 10;           // (scale, b)
   const int G = (int)gridDim.x * kRegWaves;
-  int it = (int)blockIdx.x * kRegWaves + wv;
-  if (it >= items) return;
+  const int g0 = (int)blockIdx.x * kRegWaves + wv;
+  if (g0 >= groups) return;
+  // counter c of this wave -> item: row group g0 + (c >> lsub) G, sub-item c & (2^lsub - 1) = (d << kshift) | kind
+  const int items = (((groups - 1 - g0) / G) + 1) << lsub;       // this wave's item count
+  int it = 0;
 
   cpx<float> xr[16];
   float pr[16];
   // stage 0: the first 8 spectrum values (issued behind exchange 1, when one register set of the transform is live);
   // stage 1: the other 8 and the wavelet row (issued behind the last pass, in front of the stores)
   auto fetch = [&](int item, int stage) {
-    const int b = item & 1023;
-    const int d = (item >> 10) & (p.D - 1);
-    const int tr = item >> (10 + logD);
-    const int s = p.scale0 + (tr >> kshift);
+    const int rg = g0 + (item >> lsub) * G;
+    const int b = rg & 1023;
+    const int d = (item >> kshift) & (p.D - 1);
+    const int s = p.scale0 + (rg >> 10);
     const int A = p.psiT_A[s];
     const cpx<float>* __restrict__ xrow = p.xc + ((long long)(d * 1024 + b) << 10);
     const float* __restrict__ prow = p.psiT + p.psiT_off[s] + (long long)b * A;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      if (64 * q < A && !(p.abl & 1)) {                   // wave-uniform: dead spans issue no loads
+      if (64 * q < A && !REG_ABL(1)) {                   // wave-uniform: dead spans issue no loads
         const int a = t + 64 * q;
         if ((q < 8) == (stage == 0)) xr[q] = xrow[a];
         if (stage == 1) pr[q] = prow[a < A ? a : A - 1];
@@ -107,11 +126,12 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r1_kernel(CwtRegDev p)
   fetch(it, 1);
 #pragma unroll 1
   while (true) {
-    const int b = it & 1023;
-    const int d = (it >> 10) & (p.D - 1);
-    const int tr = it >> (10 + logD);
-    const int s = p.scale0 + (tr >> kshift);
-    const int kind = tr & kshift;
+    const int rg = g0 + (it >> lsub) * G;
+    const int b = rg & 1023;
+    const int d = (it >> kshift) & (p.D - 1);
+    const int kind = it & kshift;
+    const int tr = ((rg >> 10) << kshift) | kind;
+    const int s = p.scale0 + (rg >> 10);
     const int A = p.psiT_A[s];
     cpx<float> v[16];
     // conj(X psih (i xi)^kind) = xc * psih  |  xc * (-i) * (psih * xi)      (cwt.rs:238-240, :205-208)
@@ -128,11 +148,11 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r1_kernel(CwtRegDev p)
       }
       v[q] = {x.x * ps, x.y * ps};
     }
-    if (!(p.abl & 4)) wave1024_front(v, exch, t);
-    const int nxt = it + G;
+    if (!REG_ABL(4)) wave1024_front(v, exch, t);
+    const int nxt = it + 1;
     const bool has_next = nxt < items;
     if (has_next) fetch(nxt, 0);
-    if (!(p.abl & 4)) wave1024_back(v, tw1, tw2, t);
+    if (!REG_ABL(4)) wave1024_back(v, tw1, tw2, t);
     if (has_next) fetch(nxt, 1);
     // times W_{2^20}^(b n_a), n_a = t + 64 q:  W^(b t) per lane, W^(64 b q) wave-uniform (lane q computes it)
     cpx<float> base, sq;
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r1_kernel(CwtRegDev p)
       sw.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq.x), q));
       sw.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq.y), q));
       const cpx<float> o = cmul(v[q], cmul(base, sw));
-      if (!(p.abl & 2) || o.x == 12345.678f) yrow[64 * q] = o;
+      if (!REG_ABL(2) || o.x == 12345.678f) yrow[64 * q] = o;
     }
     if (!has_next) break;
     it = nxt;
@@ -173,7 +193,14 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
   const int kshift = p.n_kinds - 1;                       // n_kinds = 1 or 2
   const int tshift = 6 + logD;                            // 64 D tiles per transform
   const int tiles = p.n_transforms << tshift;
-  int tl = blockIdx.x;
+  // D = 2: a tile reads 64-byte halves of ybuf's 128-byte lines and tile j ^ 1 reads the other halves.  Blocks go
+  // round-robin over the 8 XCDs, so blocks b and b + 8 share an L2: give THEM the two tiles of a pair (the counters
+  // showed every line fetched twice without this, profiles/r02_cwt_traffic_reg.json)
+  int bid = blockIdx.x;
+#if SSQ_R2_XCDPAIR
+  if (gridDim.x % 16 == 0) bid = 2 * (bid & 7) + 16 * (bid >> 4) + ((bid >> 3) & 1);
+#endif
+  int tl = bid;
   if (tl >= tiles) return;
   const int c_ld = tid & 15, r_ld = tid >> 4;            // transposing accesses: column fastest
   const int d_ld = c_ld & (p.D - 1), na_ld = c_ld >> logD;
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
     const int j = tile_id & ((1 << tshift) - 1);
     const cpx<float>* __restrict__ src =
         p.ybuf + ((long long)(tr << logD) << 20) + ((d_ld << 20) + (r_ld << 10) + (j * ca + na_ld));
-    if (p.abl & 8) return;
+    if REG_ABL(8) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) pf[8 * stage + i] = src[(long long)(8 * stage + i) << 16];      // rows r_ld + 64 i
   };
@@ -200,17 +227,27 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
     const int kind = tr & kshift;
 #pragma unroll
     for (int i = 0; i < 16; ++i) tile[c_ld * PT + r_ld + 64 * i] = pf[i];
+    const int nxt = tl + (int)gridDim.x;
+    const bool has_next = nxt < tiles;
+#if SSQ_R2_EARLY
+    if (has_next) {
+      fetch(nxt, 0);
+      fetch(nxt, 1);
+    }
+#endif
     __syncthreads();
     cpx<float> v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = col[t + 64 * q];
     frame_sync<false>();
-    if (!(p.abl & 32)) wave1024_front(v, col, t);
-    const int nxt = tl + (int)gridDim.x;
-    const bool has_next = nxt < tiles;
+    if (!REG_ABL(32)) wave1024_front(v, col, t);
+#if !SSQ_R2_EARLY
     if (has_next) fetch(nxt, 0);
-    if (!(p.abl & 32)) wave1024_back(v, tw1, tw2, t);
+#endif
+    if (!REG_ABL(32)) wave1024_back(v, tw1, tw2, t);
+#if !SSQ_R2_EARLY
     if (has_next) fetch(nxt, 1);
+#endif
     // D = 2: the k = P/2 term, (-1)^n Y[P/2] with n = d (mod 2), d = this wave's column (mod 2)
     cpx<float> nyq = {0.0f, 0.0f};
     const float sc = p.out_scale[s];
@@ -239,7 +276,7 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
       for (int i = 0; i < 16; ++i) {
         const cpx<float> val = tile[c_ld * PT + r_ld + 64 * i];
         const int n = n0 + ((65536 * i) << logD) - lo;
-        if ((p.abl & 16) && val.x != 12345.678f) continue;
+        if (REG_ABL(16) && val.x != 12345.678f) continue;
         if ((unsigned)n < (unsigned)cnt) row[n] = val;
       }
     }
@@ -265,8 +302,8 @@ hipError_t launch_cwt_reg_table(float* psiT, const long long* d_offT, const int*
 
 hipError_t launch_cwt_reg_inv(const CwtRegDev& p, int n_cus, hipStream_t stream) {
   if (p.n_transforms <= 0) return hipSuccess;
-  const long long items = (long long)p.n_transforms * p.D * 1024;
-  long long g1 = (items + kRegWaves - 1) / kRegWaves;
+  const long long groups = (long long)(p.n_transforms / p.n_kinds) * 1024;       // (scale, row) groups
+  long long g1 = (groups + kRegWaves - 1) / kRegWaves;
   if (g1 > n_cus) g1 = n_cus;
   hipLaunchKernelGGL(cwt_reg_r1_kernel, dim3((unsigned)g1), dim3(kRegThreads), 0, stream, p);
   long long g2 = (long long)p.n_transforms * 64 * p.D;
