@@ -79,8 +79,8 @@ long long zoom_max_q() {
   return q;
 }
 
-// SSQ_CWT_GROUP (read per call): 0 reassigns once per call (one pass over Wx / dWx from HBM) instead of group by group;
-// n > 0 sets the scales per group of the band-limited runs (default: the two-step chunk)
+// SSQ_CWT_GROUP (read per call): n > 0 reassigns every n scales right behind their transforms (while their Wx / dWx are
+// still in the Infinity Cache) instead of once per call; default 0: measured 5 % slower on C4, profiles/r02_ab_cwt_group.txt
 int ssq_group_env(int dflt) {
   const char* e = std::getenv("SSQ_CWT_GROUP");
   if (!e) return dflt;
@@ -517,8 +517,16 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     }
     return 0;
   }
-  const bool side_clear = pl->can_fuse_ssq();             // big plans: clear Tx beside the transforms here too
-  const int group = side_clear ? ssq_group_env(0) : 0;
+  const int group = pl->can_fuse_ssq() ? ssq_group_env(0) : 0;
+  // reassignment with a written-rows bitmap (first run of a row: plain store).  SSQ_CWT_SWEEP: 0 = read-modify-write
+  // of a cleared Tx; 1 (default) = bitmap, Tx cleared beside the transforms; 2 = bitmap and the kernel writes the
+  // untouched rows as zeros itself, no clear (measured slower on C4: the clear overlaps the transforms, the zero rows
+  // would not -- profiles/r02_ab_cwt_sweep.txt)
+  const char* sweep_env = std::getenv("SSQ_CWT_SWEEP");
+  const int sweep_mode = sweep_env ? std::atoi(sweep_env) : 1;
+  const bool sweep = group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
+  const bool self_zero = sweep && (sweep_mode == 2 || !pl->can_fuse_ssq());
+  const bool side_clear = pl->can_fuse_ssq() && !self_zero;   // clear Tx beside the transforms
   if (side_clear && !pl->side) {
     SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
     SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
@@ -556,7 +564,8 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
       if (side_clear) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
       q.s_begin = 0;
       q.s_end = n;
-      SSQ_HIP(launch_cwt_reassign<T>(q, st, !side_clear));
+      if (sweep) SSQ_HIP(launch_cwt_reassign_sweep<T>(q, st, self_zero));
+      else SSQ_HIP(launch_cwt_reassign<T>(q, st, !side_clear));
     }
     if (d_dbg_Wx)
       SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),

@@ -89,6 +89,12 @@ struct CwtSsqDev {
 };
 template <typename T>
 hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream, bool clear);   // clear: zero Tx first
+// the same with a per-lane bitmap of written rows: the first run in a row stores without reading.  zero_fill: the rows
+// never touched are stored as zeros at the end, so Tx needs no clear at all; otherwise Tx must be zero on entry
+template <typename T>
+bool cwt_reassign_can_sweep(int na);
+template <typename T>
+hipError_t launch_cwt_reassign_sweep(const CwtSsqDev<T>& p, hipStream_t stream, bool zero_fill);
 
 // Fused synchrosqueezing variants of inverse step B / mode Z (two-step plans): one block runs BOTH transforms (Wx and
 // dWx, ssq_cwt.rs:387-402) of one scale for its rows, applies the phase transform (ssq_cwt.rs:15-47) and the bin

@@ -286,6 +286,11 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
   }
 }
 
+// (Measured and removed: the band-limited scales with psih_s[k] == 0 for k >= 1024 as ONE zero-padded wave transform per
+// residue on this core, sharing step R2's store phase -- 0.36 ms SLOWER on C4 than the tile kernel's mode Z
+// (profiles/r02_ab_cwt_regz.txt): with one 16-wave block per CU nothing overlaps the store phase, and the short
+// transforms (Q = 16 ... 512) of the tile kernel run two blocks per CU.)
+
 hipError_t launch_cwt_reg_prep(const CwtRegDev& p, hipStream_t stream) {
   const long long n = (long long)p.D << 20;
   hipLaunchKernelGGL(cwt_reg_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);

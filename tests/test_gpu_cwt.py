@@ -319,3 +319,27 @@ def test_cwt_register_core_path(wavelet, N, monkeypatch):
     for i in range(len(scales)):
         assert np.abs(Wx[i] - Wx_o[i]).max() <= 2e-5 * np.abs(Wx_o[i]).max(), i
         assert np.abs(dWx[i] - dWx_o[i]).max() <= 2e-5 * np.abs(dWx_o[i]).max(), i
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ssq_cwt_sweep_reassignment_equals_clear_and_rmw(dtype, monkeypatch):
+    """The reassignment keeps a per-lane bitmap of the rows it has written: the first run of a row stores without reading
+    (default), optionally the untouched rows are stored as zeros by the kernel and nothing clears Tx (SSQ_CWT_SWEEP=2);
+    SSQ_CWT_SWEEP=0 is the plain read-modify-write of a cleared Tx.  Same sums in the same order: the three must be
+    identical.  N is not a multiple of 64 and na not a multiple of 32 (dead lanes, a partial bitmap word); the output
+    buffer is poisoned first."""
+    N = 5000 + 37
+    x = _sig(N, 3, dtype)
+    scales = 2.0 ** np.linspace(1, 10, 45)
+    import ssqueeze_rs_amd._lib as L
+    poison = L.pinned_empty((45, N), np.complex64 if dtype == np.float32 else np.complex128)
+    poison[:] = np.nan
+    del poison                                            # goes back to the pool the next result comes from
+    Tx, f = _rs.ssq_cwt(x, wavelet="morlet", scales=scales)
+    assert np.isfinite(Tx.view(dtype)).all()
+    assert np.count_nonzero(Tx) > 0
+    for mode in ("0", "2"):                               # read-modify-write of a cleared Tx | bitmap + own zero rows
+        monkeypatch.setenv("SSQ_CWT_SWEEP", mode)
+        Tx0, f0 = _rs.ssq_cwt(x, wavelet="morlet", scales=scales)
+        assert np.array_equal(f, f0) and np.array_equal(Tx, Tx0), mode
+
