@@ -1,6 +1,8 @@
 """Time the ssq_cwt plan on BASELINE config 4 (1 x 2^20, Morlet, 256 log scales, fp32) -- secondary metric.
     python tools/bench_cwt.py [--log2n 20] [--na 256] [--dtype f32|f64] [--steps 3]
-Prints one JSON line (bins/s, algorithmic GB/s against the 8 TB/s roof)."""
+Prints one JSON line: bins/s and BOTH rooflines -- algorithmic bytes against the 8 TB/s HBM roof and the transforms'
+flops against the fp32 / fp64 vector roof (MI355X_MICROARCH.md: 157.3 / 78.6 TFLOP/s) -- plus, for C4, the measured
+traffic per call from the committed PMC passes (profiles/r02_cwt_traffic.json)."""
 import argparse
 import ctypes as C
 import json
@@ -50,6 +52,23 @@ for _ in range(a.steps):
 dt = (time.perf_counter() - t0) / a.steps
 bins = B * na * N
 alg = B * (es * N + 2 * es * na * N)
+# flops of the algorithm as the reference runs it (cwt.rs:228-310): one forward and 2*na inverse FFTs of the padded
+# length P (5 P log2 P each) + the wavelet multiply (2*na * 6 P... counted as 2 flops per real multiply: 4 P) + the phase
+# transform and bin (~30 flops per bin)
+P = 1 << int(np.ceil(np.log2(N + N // 2)))
+lp = int(np.log2(P))
+flops = B * ((1 + 2 * na) * 5.0 * P * lp + 2 * na * 4.0 * P + 30.0 * na * N)
+vec_peak = 157.3e12 if es == 4 else 78.6e12
+traffic = None
+tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_cwt_traffic.json")
+if a.log2n == 20 and na == 256 and es == 4 and os.path.exists(tf):
+    with open(tf) as fh:
+        traffic = json.load(fh)["total_GB_per_call"] * 1e9 * B
 print(json.dumps({"workload": f"ssq_cwt morlet na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
                   "bins_per_s": bins / dt, "alg_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
+                  "roofline_hbm": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": alg / dt / 8e12, "traffic": traffic,
+                                   "traffic_over_algorithmic": (traffic / alg) if traffic else None},
+                  "roofline_vector": {"bound": "valu", "achieved": flops / dt / 1e12, "peak": vec_peak / 1e12,
+                                      "unit": "TFLOP/s", "frac": flops / dt / vec_peak},
                   "workspace_GB": wsb / 1e9}))
