@@ -712,6 +712,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #define SSQ_T0_ROTATE 1            // 1: lane 0's self-partner bins by a masked register rotation instead of selects
                                    // (re-fetching them by 16 one-lane ds_bpermute instead: +17 %, profiles/r02_ab_libs4.txt)
 #endif
+#ifndef SSQ_NT_STORE
+#define SSQ_NT_STORE 1             // 1: nontemporal Tx stores in the paired read-out (-0.7 % on the bench shape, profiles/r02_ab_nt.txt)
+#endif
 #ifndef SSQ_RO_PAIR
 #define SSQ_RO_PAIR 1              // 1: read-out of the interior 16-wave kernel with 16-byte stores (two frames per thread)
 #endif
@@ -827,7 +830,16 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
           tc[j * RS2 * PITCH + 1] = 0;
           const int r0 = (int)c0, r1 = (int)c1;
           const int i0 = (int)(c0 >> 32) - (r0 >> 31), i1 = (int)(c1 >> 32) - (r1 >> 31);
-          if (!SSQ_ABL(4)) og4[j * gstep4] = make_float4((T)r0 * sc0, (T)i0 * sc0, (T)r1 * sc1, (T)i1 * sc1);
+          if (!SSQ_ABL(4)) {
+            const float4 val = make_float4((T)r0 * sc0, (T)i0 * sc0, (T)r1 * sc1, (T)i1 * sc1);
+#if SSQ_NT_STORE
+            typedef float vf4 __attribute__((ext_vector_type(4)));
+            const vf4 nv = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(nv, reinterpret_cast<vf4*>(&og4[j * gstep4]));   // Tx is written once, never read back here
+#else
+            og4[j * gstep4] = val;
+#endif
+          }
         };
         constexpr int NFULL2 = NF / RS2;                      // 4 full sweeps
 #pragma unroll
