@@ -477,11 +477,13 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     const double lstep = n > 1 ? (std::log2(f[n - 1]) - lmin) / (double)(n - 1) : 1.0;
     q.bin_min = (T)lmin;
     q.bin_step = (T)lstep;
+    q.inv_bin_step = (T)(1.0 / lstep);
   } else {                                                                // :150-157
     const double lin_min = f[0];
     const double lstep = n > 1 ? (f[n - 1] - lin_min) / (double)(n - 1) : 1.0;
     q.bin_min = (T)lin_min;
     q.bin_step = (T)lstep;
+    q.inv_bin_step = (T)(1.0 / lstep);
   }
   q.squeezing = squeezing;
   q.flipud = flipud;

@@ -84,6 +84,7 @@ struct CwtSsqDev {
   int flipud;
   T bin_min;             // log2(f0) or f0                           (ssq_cwt.rs:142-158)
   T bin_step;
+  T inv_bin_step;        // 1 / bin_step (evaluated in fp64 on the host)
   T gamma;
   T leb_val;             // 1/na                                      (ssq_cwt.rs:201-204)
 };
