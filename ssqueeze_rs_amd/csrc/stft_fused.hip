@@ -712,6 +712,9 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #define SSQ_T0_ROTATE 1            // 1: lane 0's self-partner bins by a masked register rotation instead of selects
                                    // (re-fetching them by 16 one-lane ds_bpermute instead: +17 %, profiles/r02_ab_libs4.txt)
 #endif
+#ifndef SSQ_TX_BIAS
+#define SSQ_TX_BIAS 1              // 1: the 64-bit Tx cells of the 16-wave kernel carry RE + 2^31 (no borrow to undo at the read-out)
+#endif
 #ifndef SSQ_NT_STORE
 #define SSQ_NT_STORE 1             // 1: nontemporal Tx stores in the paired read-out (-0.7 % on the bench shape, profiles/r02_ab_nt.txt)
 #endif
@@ -779,7 +782,14 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   for (int i = tid; i < N; i += THREADS) win_lds[i] = p.win2[i];
   if (tid < 256) tw1[tid] = p.tw[((tid & 15) * (tid >> 4) * 4) & (N - 1)];
   for (int i = tid; i < 768; i += THREADS) tw2[i] = p.tw[((i & 255) * ((i >> 8) + 1)) & (N - 1)];
-  for (int i = tid; i < 2 * H::PLANE; i += THREADS) tile_re[i] = 0;
+  // 64-bit cells start at RE = 2^31 (SSQ_TX_BIAS): RE + 2^31 stays in [0, 2^32), so no borrow ever reaches the high word
+  // and the read-out takes IM = high word, RE = low word ^ 2^31 -- one instruction less per cell than undoing a borrow
+  constexpr long long CELL0 = (SSQ_TX_CELL64 && SSQ_TX_BIAS && !WKDBG) ? 0x80000000LL : 0LL;
+  if constexpr (SSQ_TX_CELL64) {
+    for (int i = tid; i < H::PLANE; i += THREADS) reinterpret_cast<long long*>(tile_re)[i] = CELL0;
+  } else {
+    for (int i = tid; i < 2 * H::PLANE; i += THREADS) tile_re[i] = 0;
+  }
   __syncthreads();
   // 8-wave variant: tiles 2i and 2i+1 hold the two 64-byte halves of the same output lines; blocks b and b + 8 run
   // on the same XCD (round-robin dispatch), so give THEM the adjacent tiles and let the halves meet in one L2
@@ -826,10 +836,15 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
         long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + 2 * fp;
         auto sweep2 = [&](int j) {
           const long long c0 = tc[j * RS2 * PITCH], c1 = tc[j * RS2 * PITCH + 1];
-          tc[j * RS2 * PITCH] = 0;
-          tc[j * RS2 * PITCH + 1] = 0;
+          tc[j * RS2 * PITCH] = CELL0;
+          tc[j * RS2 * PITCH + 1] = CELL0;
+#if SSQ_TX_BIAS
+          const int r0 = (int)c0 ^ (int)0x80000000, r1 = (int)c1 ^ (int)0x80000000;
+          const int i0 = (int)(c0 >> 32), i1 = (int)(c1 >> 32);
+#else
           const int r0 = (int)c0, r1 = (int)c1;
           const int i0 = (int)(c0 >> 32) - (r0 >> 31), i1 = (int)(c1 >> 32) - (r1 >> 31);
+#endif
           if (!SSQ_ABL(4)) {
             const float4 val = make_float4((T)r0 * sc0, (T)i0 * sc0, (T)r1 * sc1, (T)i1 * sc1);
 #if SSQ_NT_STORE
@@ -861,13 +876,18 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + f;
     auto sweep = [&](int j) {
       const long long c = tc[j * RSTEP * PITCH];
-      tc[j * RSTEP * PITCH] = 0;
-      const int ire = (int)c;
+      tc[j * RSTEP * PITCH] = CELL0;
       if constexpr (WKDBG) {
-        if (fvalid) og[j * gstep] = cpx<T>{__int_as_float(ire), __int_as_float((int)(c >> 32))};
+        if (fvalid) og[j * gstep] = cpx<T>{__int_as_float((int)c), __int_as_float((int)(c >> 32))};
         return;
       }
+#if SSQ_TX_BIAS
+      const int ire = (int)c ^ (int)0x80000000;
+      const int iim = (int)(c >> 32);
+#else
+      const int ire = (int)c;
       const int iim = (int)(c >> 32) - (ire >> 31);
+#endif
       if (fvalid) og[j * gstep] = cpx<T>{(T)ire * sc, (T)iim * sc};
     };
 #else
