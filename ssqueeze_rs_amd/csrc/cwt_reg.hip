@@ -286,6 +286,8 @@ __global__ __launch_bounds__(kRegThreads, 1) void cwt_reg_r2_kernel(CwtRegDev p)
   }
 }
 
+// (Measured and removed: R2 keeping a tile's outputs in registers and issuing their global stores only after the next tile
+// is in LDS, so that they drain behind its transform: +3 % on C4, profiles/r02_ab_cwt_latestore.txt.)
 // (Measured and removed: the band-limited scales with psih_s[k] == 0 for k >= 1024 as ONE zero-padded wave transform per
 // residue on this core, sharing step R2's store phase -- 0.36 ms SLOWER on C4 than the tile kernel's mode Z
 // (profiles/r02_ab_cwt_regz.txt): with one 16-wave block per CU nothing overlaps the store phase, and the short
