@@ -343,3 +343,23 @@ def test_ssq_cwt_sweep_reassignment_equals_clear_and_rmw(dtype, monkeypatch):
         Tx0, f0 = _rs.ssq_cwt(x, wavelet="morlet", scales=scales)
         assert np.array_equal(f, f0) and np.array_equal(Tx, Tx0), mode
 
+
+
+def test_ssq_cwt_register_core_one_residue(monkeypatch):
+    """ssq_cwt on a padded length of 2^20 (N = 600 000: ONE residue per transform on the register core, no k = P/2 term),
+    batch of two signals through one workspace: Wx / dWx to rounding against the tile kernels (SSQ_CWT_REG=0), the same
+    bins for all but a handful of elements, the same column sums of Tx."""
+    N = 600_000
+    xb = np.stack([_sig(N, 31, np.float32), _sig(N, 32, np.float32)])
+    scales = 2.0 ** np.linspace(1.0, 17.0, 24)
+    out = [_rs.ssq_cwt(x, wavelet="gmw", scales=scales, _debug=True) for x in xb]
+    monkeypatch.setenv("SSQ_CWT_REG", "0")
+    ref = [_rs.ssq_cwt(x, wavelet="gmw", scales=scales, _debug=True) for x in xb]
+    for (Tx, f, dbg), (Tx0, f0, dbg0) in zip(out, ref):
+        assert np.array_equal(f, f0)
+        for key in ("Wx", "dWx"):
+            row_max = np.abs(dbg0[key]).max(axis=1, keepdims=True)
+            assert (np.abs(dbg[key] - dbg0[key]) <= 4e-6 * row_max).all(), key
+        assert (dbg["k"] == dbg0["k"]).mean() >= 0.999
+        cs, cs0 = Tx.astype(np.complex128).sum(0), Tx0.astype(np.complex128).sum(0)
+        assert np.abs(cs - cs0).max() <= 1e-3 * np.abs(cs0).max()
