@@ -308,6 +308,8 @@ def test_cwt_register_core_path(wavelet, N, monkeypatch):
     scales = np.array([1.0, 1.7, 3.1, 6.0, 19.0, 77.0, 150.0, 900.0, 20000.0])
     Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
     Wp, _, dWp = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=True, derivative=True, rpadded=True)
+    W1, _, none = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=False)
+    assert none is None and np.array_equal(W1, Wx)       # one transform per scale: the same arithmetic per transform
     monkeypatch.setenv("SSQ_CWT_REG", "0")
     Wx0, sc0, dWx0 = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
     Wp0, _, dWp0 = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=True, derivative=True, rpadded=True)
