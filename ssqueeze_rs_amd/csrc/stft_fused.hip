@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     __builtin_amdgcn_s_setprio(0);
 #endif
     SSQ_STAMP(8);
-    __syncthreads();
+    if (!SSQ_ABL(64)) __syncthreads();      // (ablation bit 64: what ONE barrier per tile would buy -- racy, results wrong)
     SSQ_STAMP(9);
     if (!has_next) break;
     sig = nsig;
