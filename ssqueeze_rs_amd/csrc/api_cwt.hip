@@ -50,6 +50,9 @@ struct ssq_cwt_plan {
   void* d_tw1024 = nullptr;    // W_1024^j
   void* d_tw20 = nullptr;      // W_{2^20}^i, i < 1024
   int n_cus = 256;
+  // time-tiled (overlap-save) ssq path of the short-wavelet scales [os_s0, os_s1) (cwt_os.hip); empty = off
+  int os_s0 = 0, os_s1 = 0;
+  void* d_osH = nullptr;       // [os_s1 - os_s0][4096] psih on the 8192-point grid
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -206,6 +209,12 @@ int build_tables(ssq_cwt_plan* pl) {
       SSQ_HIP(hipDeviceSynchronize());
       if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
       if (int rc = upload_tw<float>(&pl->d_tw20, 1024, 1LL << 20, 1)) return rc;
+      if (pl->os_s1 > pl->os_s0) {
+        const int nos = pl->os_s1 - pl->os_s0;
+        SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)nos));
+        SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_s0, nos, pl->wavelet, nullptr));
+        SSQ_HIP(hipDeviceSynchronize());
+      }
       int dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -216,7 +225,7 @@ int build_tables(ssq_cwt_plan* pl) {
 }
 
 struct WsLayout {
-  long long xh = 0, ybuf = 0, w = 0, dw = 0, xc = 0, total = 0;
+  long long xh = 0, ybuf = 0, w = 0, dw = 0, xc = 0, os_xs = 0, total = 0;
 };
 WsLayout ws_layout(const ssq_cwt_plan* pl) {
   const long long csz = pl->dtype == SSQ_F32 ? 8 : 16;
@@ -234,6 +243,8 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   off += align((long long)pl->na * pl->N * csz);     // dWx (unfused path) or the 16-bit row indices (fused path)
   L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
   if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
+  L.os_xs = off;               // time-tiled path: the tiles' spectra
+  if (pl->os_s1 > pl->os_s0) off += align(((pl->N + kOsL - 1) / kOsL) * 4096LL * 8);
   L.total = off;
   return L;
 }
@@ -329,9 +340,10 @@ int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t s
 struct NoAfter {
   int operator()(int, int) const { return 0; }
 };
+// Scales in [skip0, skip1) are left out (the ssq path computes them by time tiles, cwt_os.hip).
 template <typename T, typename After = NoAfter>
 int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bool l1_norm, bool rpadded,
-                hipStream_t st, After after = After(), int group = 0) {
+                hipStream_t st, After after = After(), int group = 0, int skip0 = 0, int skip1 = 0) {
   p.Wx = Wx;
   p.dWx = dWx;
   p.n_kinds = dWx ? 2 : 1;
@@ -365,9 +377,13 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
   // the others through the two-step transform in chunks whose ybuf stays inside the Infinity Cache
   int s0 = 0;
   while (s0 < pl->na) {
+    if (s0 >= skip0 && s0 < skip1) {                       // (only two-step plans reach this loop)
+      s0 = skip1;
+      continue;
+    }
     const int lq = pl->zoom_logq[(size_t)s0];
     int s1 = s0 + 1;
-    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq) ++s1;
+    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq && !(s1 >= skip0 && s1 < skip1)) ++s1;
     if (lq > 0) {
       CwtDev<T> z = p;
       z.log_p2 = lq;
@@ -526,7 +542,8 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   // would not -- profiles/r02_ab_cwt_sweep.txt)
   const char* sweep_env = std::getenv("SSQ_CWT_SWEEP");
   const int sweep_mode = sweep_env ? std::atoi(sweep_env) : 1;
-  const bool sweep = group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
+  const bool os = sizeof(T) == 4 && group == 0 && pl->os_s1 > pl->os_s0;   // short-wavelet scales by time tiles
+  const bool sweep = !os && group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
   const bool self_zero = sweep && (sweep_mode == 2 || !pl->can_fuse_ssq());
   const bool side_clear = pl->can_fuse_ssq() && !self_zero;   // clear Tx beside the transforms
   if (side_clear && !pl->side) {
@@ -561,6 +578,43 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
         return 0;
       };
       if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, after, group)) return rc;   // always L1 (:405)
+    } else if (os) {
+      if constexpr (sizeof(T) == 4) {
+        // every other scale through the transforms into the workspaces ...
+        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_s0, pl->os_s1)) return rc;
+        if (d_dbg_Wx)
+          SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
+                                 hipMemcpyDeviceToDevice, st));
+        if (d_dbg_dWx)
+          SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_dWx + b * plane, dW, (size_t)plane * sizeof(cpx<T>),
+                                 hipMemcpyDeviceToDevice, st));
+        SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));           // Tx is clear from here on
+        // ... the short-wavelet scales tile by tile straight into Tx (their Wx / dWx exist only on chip) ...
+        CwtOsDev o;
+        std::memset(&o, 0, sizeof(o));
+        o.x = (const float*)d_x + b * pl->N;
+        o.xs = (cpx<float>*)(ws + L.os_xs);
+        o.H = (const float*)pl->d_osH;
+        o.tw1024 = (const cpx<float>*)pl->d_tw1024;
+        o.q = q;
+        o.dbg_Wx = d_dbg_Wx ? (cpx<float>*)d_dbg_Wx + b * plane : nullptr;
+        o.dbg_dWx = d_dbg_dWx ? (cpx<float>*)d_dbg_dWx + b * plane : nullptr;
+        o.n_signal = pl->N;
+        o.padtype = pl->padtype;
+        o.s_begin = pl->os_s0;
+        o.s_end = pl->os_s1;
+        o.xi_step = (float)((2.0 * M_PI / (double)kOsF) / pl->dt);
+        o.inv_F = 1.0f / (float)kOsF;
+        SSQ_HIP(launch_cwt_os(o, st));
+        // ... and the rest added by the column-ordered reassignment (read-modify-write)
+        q.s_begin = 0;
+        q.s_end = pl->os_s0;
+        SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
+        q.s_begin = pl->os_s1;
+        q.s_end = n;
+        SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
+      }
+      continue;
     } else {
       if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st)) return rc;
       if (side_clear) SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));
@@ -657,6 +711,35 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       pl->zoom_logq[(size_t)i] = lq;
     }
   }
+  // time-tiled ssq path: the longest run of ascending scales whose wavelet fits the tile halo in time (6 sigma_t <= halo,
+  // sigma_t = a for the Morlet wavelet, 4.943 a for the GMW: 1 / the spectral width at the peak) and is negligible at the
+  // Nyquist frequency (so that the spectrum's cut leaves no slow tail); SSQ_CWT_OS=0 switches it off
+  {
+    const char* e = std::getenv("SSQ_CWT_OS");
+    if (pl->reg && !(e && std::atoi(e) == 0)) {
+      const double sig = wavelet == SSQ_WAVELET_MORLET ? 1.0 : 4.943;
+      const double a_hi = (double)kOsHalo / (6.0 * sig);
+      const double a_lo = wavelet == SSQ_WAVELET_MORLET ? 4.0 : 1.3;
+      bool ascending = true;
+      for (int64_t i = 1; i < na; ++i) ascending = ascending && scales[i] >= scales[i - 1];
+      int best0 = 0, best1 = 0, run0 = -1;
+      for (int64_t i = 0; ascending && i <= na; ++i) {
+        const bool ok = i < na && scales[i] >= a_lo && scales[i] <= a_hi && pl->zoom_logq[(size_t)i] == 0;
+        if (ok && run0 < 0) run0 = (int)i;
+        if (!ok && run0 >= 0) {
+          if ((int)i - run0 > best1 - best0) {
+            best0 = run0;
+            best1 = (int)i;
+          }
+          run0 = -1;
+        }
+      }
+      if (best1 - best0 >= 8 && n_signal >= 2 * kOsL) {
+        pl->os_s0 = best0;
+        pl->os_s1 = best1;
+      }
+    }
+  }
   int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
   if (rc) {
     ssq_cwt_plan_destroy(pl);
@@ -686,6 +769,7 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_psiT_A);
   hipFree(pl->d_tw1024);
   hipFree(pl->d_tw20);
+  hipFree(pl->d_osH);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -736,7 +820,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

@@ -1,0 +1,223 @@
+// cwt_os.hip -- ssq_cwt of the short-wavelet scales by time tiles (overlap-save), fp32.
+//
+// The reference computes every scale as a length-P circular convolution in the frequency domain (cwt.rs:228-310) and
+// reassigns afterwards (ssq_cwt.rs:116-222); on the GPU that costs a step buffer and the Wx / dWx workspaces out to
+// memory and back (csrc/cwt_reg.hip).  For a scale whose wavelet is short in TIME -- support below
+// 2 * kOsHalo samples to fp32 accuracy, and psih(a*pi) negligible so that the Nyquist cut leaves no slow tail -- the same
+// convolution restricted to a tile of kOsL = 4096 output samples needs only the kOsF = 8192 input samples around it:
+//     Wx[n0 + i] = ifft_F( fft_F(x_pad[n0 - halo ...]) * psih(a * 2 pi k / F) )[halo + i]
+// (the F-grid samples of psih are the spectrum of the same time-domain wavelet; what differs from the reference is the
+// wavelet's tail beyond the halo, chosen below 2^-24 of its peak).  One block owns one time tile and walks ALL eligible
+// scales in ascending order: the 8192-point transforms live in LDS + registers (8 x 1024 on the per-wave core, Wx on
+// waves 0-7 and dWx on waves 8-15), the phase transform and the bin (cwt_bin.h) run on the tile in LDS, and every thread
+// keeps the run state of its 4 time columns, so Wx and dWx of these scales never reach memory and Tx receives one
+// read-modify-write per run (the block owns its columns: no atomics).
+#include "cwt_bin.h"
+#include "cwt_kernels.h"
+#include "fft_wave1024.h"
+#include "stft_kernels.h"   // load_padded
+
+namespace ssq {
+
+namespace {
+
+constexpr int kOsThreads = 1024;
+constexpr int kOsPT = 1024 + 4;      // row pitch of the [8][1024] buffers: the epilogue's (row = n & 7, n >> 3) reads hit distinct banks
+
+// forward-sign unit root e^{-2 pi i r / 8192} from W_1024 (global, cache resident) and the 8 low steps
+__device__ __forceinline__ cpx<float> os_w8192(const cpx<float>* __restrict__ tw1024, int r) {
+  // W_8192^(r & 7), r & 7 = 0..7
+  constexpr float lo[8][2] = {{1.0f, 0.0f},
+                              {0.99999970586288221916f, -0.00076699031874270453f},
+                              {0.99999882345170187925f, -0.00153398018628476561f},
+                              {0.99999735276697821091f, -0.00230096915142580450f},
+                              {0.99999529380957617151f, -0.00306795676296597627f},
+                              {0.99999264658070719110f, -0.00383494256970622610f},
+                              {0.99998941108192840321f, -0.00460192612044857020f},
+                              {0.99998558731514319867f, -0.00536890696399634140f}};
+  const cpx<float> h = tw1024[(r >> 3) & 1023];
+  const int l = r & 7;
+  return cmul(h, cpx<float>{lo[l][0], lo[l][1]});
+}
+
+}  // namespace
+
+// X_b[k], k < 4096 (analytic wavelets use no more), of every tile: xs[tile][k] = fft_8192(x_pad[n0 - halo + i])[k]
+__global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
+  __shared__ __attribute__((aligned(16))) cpx<float> zb[2][8 * kOsPT];      // kind 0 | kind 1: [row j][column]
+  __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
+  const int tid = threadIdx.x;
+  const int t = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cpx<float>* tw1 = tws;
+  cpx<float>* tw2 = tws + 256;
+  wave1024_tables(tw1, tw2, p.tw1024, tid, kOsThreads);
+  const int tile = blockIdx.x;
+  const long long n0 = (long long)tile * kOsL;                 // first output sample (unpadded time)
+  cpx<float>* __restrict__ xs = p.xs + (long long)tile * 4096;
+  __syncthreads();
+
+  // W_8192^(c j), j = 0..7, for this thread's column c (forward sign): 1, w, w^2 ... by repeated multiplication
+  cpx<float> wj[8];
+  wj[0] = {1.0f, 0.0f};
+  wj[1] = os_w8192(p.tw1024, tid);
+#pragma unroll
+  for (int j = 2; j < 8; ++j) wj[j] = cmul(wj[j - 1], wj[1]);
+
+  // ---- forward transform of the tile's 8192 input samples: n = 1024 r + c, k = j + 8 m ----
+  {
+    cpx<float> v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      v[r] = {load_padded(p.x, n0 - kOsHalo + 1024 * r + tid, p.n_signal, p.padtype), 0.0f};
+    dft8<false>(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zb[0][j * kOsPT + tid] = cmul(v[j], wj[j]);
+  }
+  __syncthreads();
+  if (wv < 8) {
+    cpx<float>* row = zb[0] + wv * kOsPT;
+    cpx<float> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = row[t + 64 * q];
+    frame_sync<false>();
+    wave1024_front(v, row, t);
+    wave1024_back(v, tw1, tw2, t);
+    // X[k = wv + 8 m], m = t + 64 q; only k < 4096 is used: m < 512
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xs[8 * (t + 64 * q) + wv] = v[q];
+  }
+  __threadfence_block();
+  __syncthreads();                                             // xs of this tile is visible to the whole block (same CU)
+
+  // ---- all eligible scales, ascending ----
+  const int kind_w = wv >> 3;                                  // waves 0-7: Wx rows, 8-15: dWx rows
+  cpx<float>* myrow = zb[kind_w] + (wv & 7) * kOsPT;
+  int k_cur[4] = {-1, -1, -1, -1};
+  cpx<float> acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+  CwtSsqDev<float> q = p.q;
+  cpx<float>* __restrict__ Tx = q.Tx;
+  auto flush = [&](int i, long long col) {
+    cpx<float>* d = Tx + (long long)k_cur[i] * q.N + col;
+    const cpx<float> tv = *d;
+    *d = {tv.x + acc[i].x, tv.y + acc[i].y};
+  };
+#pragma unroll 1
+  for (int s = p.s_begin; s < p.s_end; ++s) {
+    const float* __restrict__ Hs = p.H + (long long)(s - p.s_begin) * 4096;
+    // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < 4; on conjugated data (ifft = conj fft conj);
+    //          length-8 transform over r (4 live inputs), twiddle W_8192^(c j), rows j of both kinds
+    {
+      cpx<float> a[8], b[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 1024 * r + tid;
+        const cpx<float> x = xs[k];
+        const float h = Hs[k];
+        const cpx<float> y = {x.x * h, -x.y * h};                // conj(X H)
+        a[r] = y;
+        const float xi = (float)k * p.xi_step;                   // conj(Y * i xi) = conj(Y) * (-i) * xi
+        b[r] = {y.y * xi, -y.x * xi};
+      }
+#pragma unroll
+      for (int r = 4; r < 8; ++r) {
+        a[r] = {0.0f, 0.0f};
+        b[r] = {0.0f, 0.0f};
+      }
+      dft8<false>(a);
+      dft8<false>(b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        zb[0][j * kOsPT + tid] = cmul(a[j], wj[j]);
+        zb[1][j * kOsPT + tid] = cmul(b[j], wj[j]);
+      }
+    }
+    __syncthreads();
+    // phase 2: the 1024-point transform of row j = wave & 7 of this wave's kind; x[8 m + j] back into the row
+    {
+      cpx<float> v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = myrow[t + 64 * i];
+      frame_sync<false>();
+      wave1024_front(v, myrow, t);
+      wave1024_back(v, tw1, tw2, t);
+      const float sc = p.inv_F;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) myrow[t + 64 * i] = {v[i].x * sc, -v[i].y * sc};
+    }
+    __syncthreads();
+    // phase 3: the tile's kOsL valid samples: phase transform, bin, run merge; thread -> columns tid + 1024 i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = kOsHalo + tid + 1024 * i;                   // position inside the 8192-sample frame
+      const long long col = n0 + tid + 1024 * i;
+      const cpx<float> Wv = zb[0][(nl & 7) * kOsPT + (nl >> 3)];
+      const cpx<float> dW = zb[1][(nl & 7) * kOsPT + (nl >> 3)];
+      if (col < q.N) {
+        if (p.dbg_Wx) p.dbg_Wx[(long long)s * q.N + col] = Wv;
+        if (p.dbg_dWx) p.dbg_dWx[(long long)s * q.N + col] = dW;
+        float w;
+        const int kk = reassign_bin(q, Wv, dW, w);
+        if (q.wk) q.wk[(long long)s * q.N + col] = {w, (float)kk};
+        if (kk != k_cur[i]) {
+          if (k_cur[i] >= 0) flush(i, col);
+          k_cur[i] = kk;
+          acc[i] = {0.0f, 0.0f};
+        }
+        if (kk >= 0) {
+          if (q.squeezing == 1) {
+            acc[i].x += q.leb_val;
+          } else {
+            acc[i].x += Wv.x;
+            acc[i].y += Wv.y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long col = n0 + tid + 1024 * i;
+    if (col < q.N && k_cur[i] >= 0) flush(i, col);
+  }
+}
+
+// H[s - s_begin][k] = psih(scale_s * 2 pi k / 8192), k < 4096 (fp64, rounded once), the formulas of wavelet_table_kernel
+__global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restrict__ scales, int s_begin, int n_scales,
+                                    int wavelet) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int sl = blockIdx.y;
+  if (sl >= n_scales || k >= 4096) return;
+  const double xi = (double)k * (2.0 * 3.14159265358979323846 / (double)kOsF);
+  const double w = scales[s_begin + sl] * xi;
+  double v = 0.0;
+  if (wavelet == 1) {                                   // "morlet"  cwt.rs:497-520
+    if (w >= 0.0) {
+      const double mu = 6.0;
+      const double norm = pow(3.14159265358979323846, -0.25) * 1.41421356237309504880;
+      const double k_exp = exp(-0.5 * mu * mu);
+      const double wm = w - mu;
+      v = norm * (exp(-0.5 * (wm * wm)) - k_exp * exp(-0.5 * (w * w)));
+    }
+  } else {                                              // "gmw" | _  cwt.rs:522-542
+    if (w > 0.0) v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
+  }
+  H[(long long)sl * 4096 + k] = (float)v;
+}
+
+hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, hipStream_t stream) {
+  if (n_scales <= 0) return hipSuccess;
+  hipLaunchKernelGGL(cwt_os_table_kernel, dim3(4096 / 256, (unsigned)n_scales), dim3(256), 0, stream, H, d_scales, s_begin,
+                     n_scales, wavelet);
+  return hipGetLastError();
+}
+
+hipError_t launch_cwt_os(const CwtOsDev& p, hipStream_t stream) {
+  if (p.s_end <= p.s_begin) return hipSuccess;
+  const long long tiles = (p.q.N + kOsL - 1) / kOsL;
+  hipLaunchKernelGGL(cwt_os_kernel, dim3((unsigned)tiles), dim3(kOsThreads), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace ssq

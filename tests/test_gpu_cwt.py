@@ -365,3 +365,35 @@ def test_ssq_cwt_register_core_one_residue(monkeypatch):
         assert (dbg["k"] == dbg0["k"]).mean() >= 0.999
         cs, cs0 = Tx.astype(np.complex128).sum(0), Tx0.astype(np.complex128).sum(0)
         assert np.abs(cs - cs0).max() <= 1e-3 * np.abs(cs0).max()
+
+
+@pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
+def test_ssq_cwt_time_tiled_scales(wavelet, monkeypatch):
+    """fp32 plans at C4's geometry run the scales whose wavelet is short in time by overlap-save tiles
+    (csrc/cwt_os.hip: 4096 output samples from 8192-point transforms, bins and run merging on chip, Wx / dWx of those
+    scales never in memory); SSQ_CWT_OS=0 keeps the frequency-domain path for every scale.  The two differ only by the
+    wavelet's tail beyond the tile halo (< 1e-8 of its peak): Wx / dWx per scale to fp32 rounding, the same bins for
+    all but a handful of elements, the same Tx column sums -- and the oracle's Wx on a subset of the tiled scales.
+    N is not a multiple of the tile length (a partial last tile)."""
+    N = (1 << 20) - 1234
+    x = _sig(N, 41, np.float32)
+    scales = 2.0 ** np.linspace(1.0, 19.0, 64)
+    Tx, f, dbg = _rs.ssq_cwt(x, wavelet=wavelet, scales=scales, _debug=True)
+    monkeypatch.setenv("SSQ_CWT_OS", "0")
+    Tx0, f0, dbg0 = _rs.ssq_cwt(x, wavelet=wavelet, scales=scales, _debug=True)
+    assert np.array_equal(f, f0)
+    differ = [i for i in range(64) if not np.array_equal(dbg["Wx"][i], dbg0["Wx"][i])]
+    assert len(differ) >= 8                               # the tiled path really ran (other scales are bit-identical)
+    for key in ("Wx", "dWx"):
+        row_max = np.abs(dbg0[key]).max(axis=1, keepdims=True)
+        assert (np.abs(dbg[key] - dbg0[key]) <= 6e-6 * row_max).all(), key
+    assert (dbg["k"] == dbg0["k"]).mean() >= 0.999
+    cs, cs0 = Tx.astype(np.complex128).sum(0), Tx0.astype(np.complex128).sum(0)
+    assert np.abs(cs - cs0).max() <= 1e-3 * np.abs(cs0).max()
+    re, re0 = (np.abs(Tx.astype(np.complex128)) ** 2).sum(1), (np.abs(Tx0.astype(np.complex128)) ** 2).sum(1)
+    assert np.abs(re - re0).max() <= 2e-3 * re0.max()
+    sub = np.array(differ[:: max(1, len(differ) // 4)])
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), wavelet, scales=scales[sub], derivative=True)
+    for j, i in enumerate(sub):
+        assert np.abs(dbg["Wx"][i] - Wx_o[j]).max() <= 2e-5 * np.abs(Wx_o[j]).max(), i
+        assert np.abs(dbg["dWx"][i] - dWx_o[j]).max() <= 2e-5 * np.abs(dWx_o[j]).max(), i
