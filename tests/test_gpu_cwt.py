@@ -354,6 +354,7 @@ def test_ssq_cwt_register_core_one_residue(monkeypatch):
     N = 600_000
     xb = np.stack([_sig(N, 31, np.float32), _sig(N, 32, np.float32)])
     scales = 2.0 ** np.linspace(1.0, 17.0, 24)
+    monkeypatch.setenv("SSQ_CWT_OS", "0")               # (the time-tiled path has its own test)
     out = [_rs.ssq_cwt(x, wavelet="gmw", scales=scales, _debug=True) for x in xb]
     monkeypatch.setenv("SSQ_CWT_REG", "0")
     ref = [_rs.ssq_cwt(x, wavelet="gmw", scales=scales, _debug=True) for x in xb]
