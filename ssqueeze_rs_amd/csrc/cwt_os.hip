@@ -97,14 +97,24 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
   cpx<float> acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
   CwtSsqDev<float> q = p.q;
   cpx<float>* __restrict__ Tx = q.Tx;
+  // (no-return float atomics instead of the read-modify-write of a finished run: 0.75 ms SLOWER on C4,
+  // profiles/r02_ab_cwt_os.txt -- 1.3e8 L2 atomics cost more than the loads they replace)
   auto flush = [&](int i, long long col) {
     cpx<float>* d = Tx + (long long)k_cur[i] * q.N + col;
     const cpx<float> tv = *d;
     *d = {tv.x + acc[i].x, tv.y + acc[i].y};
   };
+  // this thread's 4 spectrum values stay in registers for all scales; the wavelet row of the NEXT scale is requested
+  // behind the transform of the current one
+  cpx<float> xk[4];
+  float hk[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    xk[r] = xs[1024 * r + tid];
+    hk[r] = p.H[1024 * r + tid];
+  }
 #pragma unroll 1
   for (int s = p.s_begin; s < p.s_end; ++s) {
-    const float* __restrict__ Hs = p.H + (long long)(s - p.s_begin) * 4096;
     // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < 4; on conjugated data (ifft = conj fft conj);
     //          length-8 transform over r (4 live inputs), twiddle W_8192^(c j), rows j of both kinds
     {
@@ -112,8 +122,8 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 1024 * r + tid;
-        const cpx<float> x = xs[k];
-        const float h = Hs[k];
+        const cpx<float> x = xk[r];
+        const float h = hk[r];
         const cpx<float> y = {x.x * h, -x.y * h};                // conj(X H)
         a[r] = y;
         const float xi = (float)k * p.xi_step;                   // conj(Y * i xi) = conj(Y) * (-i) * xi
@@ -140,19 +150,30 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
       for (int i = 0; i < 16; ++i) v[i] = myrow[t + 64 * i];
       frame_sync<false>();
       wave1024_front(v, myrow, t);
+      if (s + 1 < p.s_end) {
+        const float* __restrict__ Hn = p.H + (long long)(s + 1 - p.s_begin) * 4096;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hk[r] = Hn[1024 * r + tid];
+      }
       wave1024_back(v, tw1, tw2, t);
       const float sc = p.inv_F;
 #pragma unroll
       for (int i = 0; i < 16; ++i) myrow[t + 64 * i] = {v[i].x * sc, -v[i].y * sc};
     }
     __syncthreads();
-    // phase 3: the tile's kOsL valid samples: phase transform, bin, run merge; thread -> columns tid + 1024 i
+    // phase 3: the tile's kOsL valid samples: phase transform, bin, run merge; thread -> columns tid + 1024 i.
+    // The runs that end at this scale are collected first and read-modify-written together (one memory round trip
+    // for the four columns instead of one per column)
+    cpx<float>* fl_ptr[4];
+    cpx<float> fl_val[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = kOsHalo + tid + 1024 * i;                   // position inside the 8192-sample frame
       const long long col = n0 + tid + 1024 * i;
       const cpx<float> Wv = zb[0][(nl & 7) * kOsPT + (nl >> 3)];
       const cpx<float> dW = zb[1][(nl & 7) * kOsPT + (nl >> 3)];
+      fl_ptr[i] = nullptr;
+      fl_val[i] = {0.0f, 0.0f};
       if (col < q.N) {
         if (p.dbg_Wx) p.dbg_Wx[(long long)s * q.N + col] = Wv;
         if (p.dbg_dWx) p.dbg_dWx[(long long)s * q.N + col] = dW;
@@ -160,7 +181,10 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
         const int kk = reassign_bin(q, Wv, dW, w);
         if (q.wk) q.wk[(long long)s * q.N + col] = {w, (float)kk};
         if (kk != k_cur[i]) {
-          if (k_cur[i] >= 0) flush(i, col);
+          if (k_cur[i] >= 0) {
+            fl_ptr[i] = Tx + (long long)k_cur[i] * q.N + col;
+            fl_val[i] = acc[i];
+          }
           k_cur[i] = kk;
           acc[i] = {0.0f, 0.0f};
         }
@@ -173,6 +197,14 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
           }
         }
       }
+    }
+    {
+      cpx<float> tv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tv[i] = fl_ptr[i] ? *fl_ptr[i] : cpx<float>{0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (fl_ptr[i]) *fl_ptr[i] = {tv[i].x + fl_val[i].x, tv[i].y + fl_val[i].y};
     }
     __syncthreads();
   }
