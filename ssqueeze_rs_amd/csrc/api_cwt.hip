@@ -185,6 +185,14 @@ int build_tables(ssq_cwt_plan* pl) {
     SSQ_HIP(hipDeviceSynchronize());
   }
   if constexpr (sizeof(T) == 4) {
+    if (pl->os_s1 > pl->os_s0) {                               // time-tiled ssq path (any two-step fp32 plan)
+      const int nos = pl->os_s1 - pl->os_s0;
+      if (!pl->reg)
+        if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
+      SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)nos));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_s0, nos, pl->wavelet, nullptr));
+      SSQ_HIP(hipDeviceSynchronize());
+    }
     if (pl->reg && pl->na > 0) {
       std::vector<int> A((size_t)pl->na, 0);
       std::vector<long long> offT((size_t)pl->na, 0);
@@ -209,12 +217,6 @@ int build_tables(ssq_cwt_plan* pl) {
       SSQ_HIP(hipDeviceSynchronize());
       if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
       if (int rc = upload_tw<float>(&pl->d_tw20, 1024, 1LL << 20, 1)) return rc;
-      if (pl->os_s1 > pl->os_s0) {
-        const int nos = pl->os_s1 - pl->os_s0;
-        SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)nos));
-        SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_s0, nos, pl->wavelet, nullptr));
-        SSQ_HIP(hipDeviceSynchronize());
-      }
       int dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -716,7 +718,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   // Nyquist frequency (so that the spectrum's cut leaves no slow tail); SSQ_CWT_OS=0 switches it off
   {
     const char* e = std::getenv("SSQ_CWT_OS");
-    if (pl->reg && !(e && std::atoi(e) == 0)) {
+    if (dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0)) {
       const double sig = wavelet == SSQ_WAVELET_MORLET ? 1.0 : 4.943;
       const double a_hi = (double)kOsHalo / (6.0 * sig);
       const double a_lo = wavelet == SSQ_WAVELET_MORLET ? 4.0 : 1.3;
@@ -734,7 +736,8 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
           run0 = -1;
         }
       }
-      if (best1 - best0 >= 8 && n_signal >= 2 * kOsL) {
+      // (a block walks the scales of ITS tile one after the other: worth it only with enough tiles to fill the chip)
+      if (best1 - best0 >= 8 && n_signal >= 64LL * kOsL) {
         pl->os_s0 = best0;
         pl->os_s1 = best1;
       }
