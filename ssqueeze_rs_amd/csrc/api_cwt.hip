@@ -51,8 +51,10 @@ struct ssq_cwt_plan {
   void* d_tw20 = nullptr;      // W_{2^20}^i, i < 1024
   int n_cus = 256;
   // time-tiled (overlap-save) ssq path of the short-wavelet scales [os_s0, os_s1) (cwt_os.hip); empty = off
-  int os_s0 = 0, os_s1 = 0;
-  void* d_osH = nullptr;       // [os_s1 - os_s0][4096] psih on the 8192-point grid
+  // [os_s0, os_mid): 4096-point tiles (halo 1024, two blocks per CU); [os_mid, os_s1): 8192-point tiles (halo 2048)
+  int os_s0 = 0, os_mid = 0, os_s1 = 0;
+  void* d_osH4 = nullptr;      // [os_mid - os_s0][2048] psih on the 4096-point grid
+  void* d_osH = nullptr;       // [os_s1 - os_mid][4096] psih on the 8192-point grid
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -186,11 +188,13 @@ int build_tables(ssq_cwt_plan* pl) {
   }
   if constexpr (sizeof(T) == 4) {
     if (pl->os_s1 > pl->os_s0) {                               // time-tiled ssq path (any two-step fp32 plan)
-      const int nos = pl->os_s1 - pl->os_s0;
+      const int n4 = pl->os_mid - pl->os_s0, n8 = pl->os_s1 - pl->os_mid;
       if (!pl->reg)
         if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
-      SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)nos));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_s0, nos, pl->wavelet, nullptr));
+      SSQ_HIP(hipMalloc(&pl->d_osH4, sizeof(float) * 2048 * (size_t)(n4 > 0 ? n4 : 1)));
+      SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)(n8 > 0 ? n8 : 1)));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH4, pl->d_scales, pl->os_s0, n4, pl->wavelet, 4, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_mid, n8, pl->wavelet, 8, nullptr));
       SSQ_HIP(hipDeviceSynchronize());
     }
     if (pl->reg && pl->na > 0) {
@@ -246,7 +250,7 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
   if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
   L.os_xs = off;               // time-tiled path: the tiles' spectra
-  if (pl->os_s1 > pl->os_s0) off += align(((pl->N + kOsL - 1) / kOsL) * 4096LL * 8);
+  if (pl->os_s1 > pl->os_s0) off += align(((pl->N + 2047) / 2048) * 2048LL * 8);   // (either geometry: N rounded up)
   L.total = off;
   return L;
 }
@@ -596,18 +600,21 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
         std::memset(&o, 0, sizeof(o));
         o.x = (const float*)d_x + b * pl->N;
         o.xs = (cpx<float>*)(ws + L.os_xs);
-        o.H = (const float*)pl->d_osH;
         o.tw1024 = (const cpx<float>*)pl->d_tw1024;
         o.q = q;
         o.dbg_Wx = d_dbg_Wx ? (cpx<float>*)d_dbg_Wx + b * plane : nullptr;
         o.dbg_dWx = d_dbg_dWx ? (cpx<float>*)d_dbg_dWx + b * plane : nullptr;
         o.n_signal = pl->N;
         o.padtype = pl->padtype;
-        o.s_begin = pl->os_s0;
-        o.s_end = pl->os_s1;
-        o.xi_step = (float)((2.0 * M_PI / (double)kOsF) / pl->dt);
-        o.inv_F = 1.0f / (float)kOsF;
-        SSQ_HIP(launch_cwt_os(o, st));
+        for (int rows = 4; rows <= 8; rows += 4) {               // ascending scales: the short tiles first
+          const double F = 1024.0 * rows;
+          o.H = (const float*)(rows == 4 ? pl->d_osH4 : pl->d_osH);
+          o.s_begin = rows == 4 ? pl->os_s0 : pl->os_mid;
+          o.s_end = rows == 4 ? pl->os_mid : pl->os_s1;
+          o.xi_step = (float)((2.0 * M_PI / F) / pl->dt);
+          o.inv_F = (float)(1.0 / F);
+          SSQ_HIP(launch_cwt_os(o, rows, st));
+        }
         // ... and the rest added by the column-ordered reassignment (read-modify-write)
         q.s_begin = 0;
         q.s_end = pl->os_s0;
@@ -740,6 +747,13 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       if (best1 - best0 >= 8 && n_signal >= 64LL * kOsL) {
         pl->os_s0 = best0;
         pl->os_s1 = best1;
+        // the scales whose wavelet fits HALF the halo take the 4096-point tiles (SSQ_CWT_OS_ROWS=8: all on 8192 points)
+        const char* er = std::getenv("SSQ_CWT_OS_ROWS");
+        int mid = best0;
+        if (!(er && std::atoi(er) == 8))
+          while (mid < best1 && scales[mid] <= 0.5 * a_hi) ++mid;
+        if (mid - best0 < 8) mid = best0;
+        pl->os_mid = mid;
       }
     }
   }
@@ -773,6 +787,7 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_tw1024);
   hipFree(pl->d_tw20);
   hipFree(pl->d_osH);
+  hipFree(pl->d_osH4);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -823,7 +838,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

@@ -136,13 +136,14 @@ hipError_t launch_cwt_reg_table(float* psiT, const long long* d_offT, const int*
 hipError_t launch_cwt_reg_inv(const CwtRegDev& p, int n_cus, hipStream_t stream);             // R1 + R2 of p.n_transforms
 
 // ---- cwt_os.hip: ssq_cwt of the short-wavelet scales by time tiles (overlap-save), fp32 ----
-constexpr int kOsF = 8192;        // transform length of a tile
-constexpr int kOsL = 4096;        // output samples of a tile
+// geometry of `rows` = 8 | 4: transform length 1024 rows, output samples 512 rows per tile, halo 256 rows on either side
+constexpr int kOsF = 8192;        // rows = 8
+constexpr int kOsL = 4096;
 constexpr int kOsHalo = 2048;     // input samples on either side: the wavelet's time support must fit
 struct CwtOsDev {
   const float* x;              // [n_signal] one real signal
-  cpx<float>* xs;              // scratch [tiles][4096]: the tiles' spectra (k < 4096)
-  const float* H;              // [s_end - s_begin][4096] psih(scale * 2 pi k / 8192)
+  cpx<float>* xs;              // scratch [tiles][F / 2]: the tiles' spectra (k < F / 2)
+  const float* H;              // [s_end - s_begin][F / 2] psih(scale * 2 pi k / F)
   const cpx<float>* tw1024;    // W_1024^j
   CwtSsqDev<float> q;          // binning parameters, Tx (zero or partial sums on entry), optional (w, k) hook
   cpx<float>* dbg_Wx;          // optional [na][N] debug copies
@@ -150,10 +151,11 @@ struct CwtOsDev {
   long long n_signal;
   int padtype;
   int s_begin, s_end;          // scales of this launch (ascending)
-  float xi_step;               // (2 pi / 8192) / dt
-  float inv_F;                 // 1 / 8192
+  float xi_step;               // (2 pi / F) / dt
+  float inv_F;                 // 1 / F
 };
-hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, hipStream_t stream);
-hipError_t launch_cwt_os(const CwtOsDev& p, hipStream_t stream);
+hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
+                               hipStream_t stream);
+hipError_t launch_cwt_os(const CwtOsDev& p, int rows, hipStream_t stream);
 
 }  // namespace ssq

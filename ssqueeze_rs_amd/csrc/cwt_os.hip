@@ -12,6 +12,9 @@
 // waves 0-7 and dWx on waves 8-15), the phase transform and the bin (cwt_bin.h) run on the tile in LDS, and every thread
 // keeps the run state of its 4 time columns, so Wx and dWx of these scales never reach memory and Tx receives one
 // read-modify-write per run (the block owns its columns: no atomics).
+// Two geometries (template R = rows of 1024 points): R = 8 as above (16 waves, one block per CU), and R = 4 -- 4096-point
+// transforms, 2048 output samples, a 1024-sample halo, 8 waves, TWO blocks per CU whose phases overlap -- for the scales
+// whose wavelet fits the shorter halo.
 #include "cwt_bin.h"
 #include "cwt_kernels.h"
 #include "fft_wave1024.h"
@@ -21,12 +24,21 @@ namespace ssq {
 
 namespace {
 
-constexpr int kOsThreads = 1024;
-constexpr int kOsPT = 1024 + 4;      // row pitch of the [8][1024] buffers: the epilogue's (row = n & 7, n >> 3) reads hit distinct banks
+template <int R>
+struct OsCfg {
+  static_assert(R == 4 || R == 8, "rows");
+  static constexpr int F = 1024 * R;          // transform length
+  static constexpr int L = F / 2;             // output samples per tile
+  static constexpr int HALO = F / 4;
+  static constexpr int THREADS = 128 * R;     // 2 R waves: R rows of Wx, R rows of dWx
+  static constexpr int PT = 1024 + 32 / R;    // row pitch: the epilogue's (row = n % R, n / R) reads hit distinct banks
+  static constexpr int LOGR = R == 8 ? 3 : 2;
+};
 
-// forward-sign unit root e^{-2 pi i r / 8192} from W_1024 (global, cache resident) and the 8 low steps
-__device__ __forceinline__ cpx<float> os_w8192(const cpx<float>* __restrict__ tw1024, int r) {
-  // W_8192^(r & 7), r & 7 = 0..7
+// forward-sign unit root e^{-2 pi i r / (1024 R)} from W_1024 (global, cache resident) and the R low steps
+template <int R>
+__device__ __forceinline__ cpx<float> os_wF(const cpx<float>* __restrict__ tw1024, int r) {
+  // W_8192^l, l = 0..7 (R = 4 uses the even entries: W_4096^l = W_8192^(2 l))
   constexpr float lo[8][2] = {{1.0f, 0.0f},
                               {0.99999970586288221916f, -0.00076699031874270453f},
                               {0.99999882345170187925f, -0.00153398018628476561f},
@@ -35,64 +47,79 @@ __device__ __forceinline__ cpx<float> os_w8192(const cpx<float>* __restrict__ tw
                               {0.99999264658070719110f, -0.00383494256970622610f},
                               {0.99998941108192840321f, -0.00460192612044857020f},
                               {0.99998558731514319867f, -0.00536890696399634140f}};
-  const cpx<float> h = tw1024[(r >> 3) & 1023];
-  const int l = r & 7;
+  constexpr int LOGR = R == 8 ? 3 : 2;
+  const cpx<float> h = tw1024[(r >> LOGR) & 1023];
+  const int l = (r & (R - 1)) * (8 / R);
   return cmul(h, cpx<float>{lo[l][0], lo[l][1]});
+}
+
+template <int R>
+__device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
+  if constexpr (R == 8) dft8<false>(v);
+  else dft4<false>(v[0], v[1], v[2], v[3]);
 }
 
 }  // namespace
 
-// X_b[k], k < 4096 (analytic wavelets use no more), of every tile: xs[tile][k] = fft_8192(x_pad[n0 - halo + i])[k]
-__global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
-  __shared__ __attribute__((aligned(16))) cpx<float> zb[2][8 * kOsPT];      // kind 0 | kind 1: [row j][column]
+// One block = one time tile of OsCfg<R>::L output samples; see the header.
+template <int R>
+__global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p) {
+  using K = OsCfg<R>;
+  constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR, H2 = R / 2;
+  __shared__ __attribute__((aligned(16))) cpx<float> zb[2][R * PT];         // kind 0 | kind 1: [row j][column]
   __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
   const int tid = threadIdx.x;
   const int t = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   cpx<float>* tw1 = tws;
   cpx<float>* tw2 = tws + 256;
-  wave1024_tables(tw1, tw2, p.tw1024, tid, kOsThreads);
+  wave1024_tables(tw1, tw2, p.tw1024, tid, THREADS);
   const int tile = blockIdx.x;
-  const long long n0 = (long long)tile * kOsL;                 // first output sample (unpadded time)
-  cpx<float>* __restrict__ xs = p.xs + (long long)tile * 4096;
+  const long long n0 = (long long)tile * L;                    // first output sample (unpadded time)
+  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2);
   __syncthreads();
 
-  // W_8192^(c j), j = 0..7, for this thread's column c (forward sign): 1, w, w^2 ... by repeated multiplication
-  cpx<float> wj[8];
-  wj[0] = {1.0f, 0.0f};
-  wj[1] = os_w8192(p.tw1024, tid);
+  // W_F^(c j), j < R, for the columns c = tid + THREADS * u this thread transforms (forward sign): 1, w, w^2 ...
+  constexpr int CPT = 1024 / THREADS;                          // columns per thread in the length-R transforms: 1 or 2
+  cpx<float> wj[CPT][R];
 #pragma unroll
-  for (int j = 2; j < 8; ++j) wj[j] = cmul(wj[j - 1], wj[1]);
+  for (int u = 0; u < CPT; ++u) {
+    wj[u][0] = {1.0f, 0.0f};
+    wj[u][1] = os_wF<R>(p.tw1024, tid + THREADS * u);
+#pragma unroll
+    for (int j = 2; j < R; ++j) wj[u][j] = cmul(wj[u][j - 1], wj[u][1]);
+  }
 
-  // ---- forward transform of the tile's 8192 input samples: n = 1024 r + c, k = j + 8 m ----
-  {
-    cpx<float> v[8];
+  // ---- forward transform of the tile's F input samples: n = 1024 r + c, k = j + R m ----
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-      v[r] = {load_padded(p.x, n0 - kOsHalo + 1024 * r + tid, p.n_signal, p.padtype), 0.0f};
-    dft8<false>(v);
+  for (int u = 0; u < CPT; ++u) {
+    const int c = tid + THREADS * u;
+    cpx<float> v[R];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) zb[0][j * kOsPT + tid] = cmul(v[j], wj[j]);
+    for (int r = 0; r < R; ++r) v[r] = {load_padded(p.x, n0 - HALO + 1024 * r + c, p.n_signal, p.padtype), 0.0f};
+    os_dft<R>(v);
+#pragma unroll
+    for (int j = 0; j < R; ++j) zb[0][j * PT + c] = cmul(v[j], wj[u][j]);
   }
   __syncthreads();
-  if (wv < 8) {
-    cpx<float>* row = zb[0] + wv * kOsPT;
+  if (wv < R) {
+    cpx<float>* row = zb[0] + wv * PT;
     cpx<float> v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = row[t + 64 * q];
     frame_sync<false>();
     wave1024_front(v, row, t);
     wave1024_back(v, tw1, tw2, t);
-    // X[k = wv + 8 m], m = t + 64 q; only k < 4096 is used: m < 512
+    // X[k = wv + R m], m = t + 64 q; only k < F / 2 is used: m < 512
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xs[8 * (t + 64 * q) + wv] = v[q];
+    for (int q = 0; q < 8; ++q) xs[R * (t + 64 * q) + wv] = v[q];
   }
   __threadfence_block();
   __syncthreads();                                             // xs of this tile is visible to the whole block (same CU)
 
   // ---- all eligible scales, ascending ----
-  const int kind_w = wv >> 3;                                  // waves 0-7: Wx rows, 8-15: dWx rows
-  cpx<float>* myrow = zb[kind_w] + (wv & 7) * kOsPT;
+  const int kind_w = wv >= R ? 1 : 0;                          // waves 0 .. R-1: Wx rows, R .. 2R-1: dWx rows
+  cpx<float>* myrow = zb[kind_w] + (wv & (R - 1)) * PT;
   int k_cur[4] = {-1, -1, -1, -1};
   cpx<float> acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
   CwtSsqDev<float> q = p.q;
@@ -104,46 +131,50 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
     const cpx<float> tv = *d;
     *d = {tv.x + acc[i].x, tv.y + acc[i].y};
   };
-  // this thread's 4 spectrum values stay in registers for all scales; the wavelet row of the NEXT scale is requested
+  // this thread's spectrum values stay in registers for all scales; the wavelet row of the NEXT scale is requested
   // behind the transform of the current one
-  cpx<float> xk[4];
-  float hk[4];
+  cpx<float> xk[CPT][H2];
+  float hk[CPT][H2];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    xk[r] = xs[1024 * r + tid];
-    hk[r] = p.H[1024 * r + tid];
-  }
+  for (int u = 0; u < CPT; ++u)
+#pragma unroll
+    for (int r = 0; r < H2; ++r) {
+      xk[u][r] = xs[1024 * r + tid + THREADS * u];
+      hk[u][r] = p.H[1024 * r + tid + THREADS * u];
+    }
 #pragma unroll 1
   for (int s = p.s_begin; s < p.s_end; ++s) {
-    // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < 4; on conjugated data (ifft = conj fft conj);
-    //          length-8 transform over r (4 live inputs), twiddle W_8192^(c j), rows j of both kinds
-    {
-      cpx<float> a[8], b[8];
+    // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < R / 2; on conjugated data (ifft = conj fft
+    //          conj); length-R transform over r (R / 2 live inputs), twiddle W_F^(c j), rows j of both kinds
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 1024 * r + tid;
-        const cpx<float> x = xk[r];
-        const float h = hk[r];
+    for (int u = 0; u < CPT; ++u) {
+      const int c = tid + THREADS * u;
+      cpx<float> a[R], b[R];
+#pragma unroll
+      for (int r = 0; r < H2; ++r) {
+        const int k = 1024 * r + c;
+        const cpx<float> x = xk[u][r];
+        const float h = hk[u][r];
         const cpx<float> y = {x.x * h, -x.y * h};                // conj(X H)
         a[r] = y;
         const float xi = (float)k * p.xi_step;                   // conj(Y * i xi) = conj(Y) * (-i) * xi
         b[r] = {y.y * xi, -y.x * xi};
       }
 #pragma unroll
-      for (int r = 4; r < 8; ++r) {
+      for (int r = H2; r < R; ++r) {
         a[r] = {0.0f, 0.0f};
         b[r] = {0.0f, 0.0f};
       }
-      dft8<false>(a);
-      dft8<false>(b);
+      os_dft<R>(a);
+      os_dft<R>(b);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        zb[0][j * kOsPT + tid] = cmul(a[j], wj[j]);
-        zb[1][j * kOsPT + tid] = cmul(b[j], wj[j]);
+      for (int j = 0; j < R; ++j) {
+        zb[0][j * PT + c] = cmul(a[j], wj[u][j]);
+        zb[1][j * PT + c] = cmul(b[j], wj[u][j]);
       }
     }
     __syncthreads();
-    // phase 2: the 1024-point transform of row j = wave & 7 of this wave's kind; x[8 m + j] back into the row
+    // phase 2: the 1024-point transform of this wave's row of its kind; x[R m + j] back into the row
     {
       cpx<float> v[16];
 #pragma unroll
@@ -151,9 +182,11 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
       frame_sync<false>();
       wave1024_front(v, myrow, t);
       if (s + 1 < p.s_end) {
-        const float* __restrict__ Hn = p.H + (long long)(s + 1 - p.s_begin) * 4096;
+        const float* __restrict__ Hn = p.H + (long long)(s + 1 - p.s_begin) * (F / 2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hk[r] = Hn[1024 * r + tid];
+        for (int u = 0; u < CPT; ++u)
+#pragma unroll
+          for (int r = 0; r < H2; ++r) hk[u][r] = Hn[1024 * r + tid + THREADS * u];
       }
       wave1024_back(v, tw1, tw2, t);
       const float sc = p.inv_F;
@@ -161,17 +194,17 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
       for (int i = 0; i < 16; ++i) myrow[t + 64 * i] = {v[i].x * sc, -v[i].y * sc};
     }
     __syncthreads();
-    // phase 3: the tile's kOsL valid samples: phase transform, bin, run merge; thread -> columns tid + 1024 i.
+    // phase 3: the tile's L valid samples: phase transform, bin, run merge; thread -> columns tid + THREADS i.
     // The runs that end at this scale are collected first and read-modify-written together (one memory round trip
     // for the four columns instead of one per column)
     cpx<float>* fl_ptr[4];
     cpx<float> fl_val[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int nl = kOsHalo + tid + 1024 * i;                   // position inside the 8192-sample frame
-      const long long col = n0 + tid + 1024 * i;
-      const cpx<float> Wv = zb[0][(nl & 7) * kOsPT + (nl >> 3)];
-      const cpx<float> dW = zb[1][(nl & 7) * kOsPT + (nl >> 3)];
+      const int nl = HALO + tid + THREADS * i;                   // position inside the F-sample frame
+      const long long col = n0 + tid + THREADS * i;
+      const cpx<float> Wv = zb[0][(nl & (R - 1)) * PT + (nl >> LOGR)];
+      const cpx<float> dW = zb[1][(nl & (R - 1)) * PT + (nl >> LOGR)];
       fl_ptr[i] = nullptr;
       fl_val[i] = {0.0f, 0.0f};
       if (col < q.N) {
@@ -210,18 +243,18 @@ __global__ __launch_bounds__(kOsThreads, 1) void cwt_os_kernel(CwtOsDev p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long col = n0 + tid + 1024 * i;
+    const long long col = n0 + tid + THREADS * i;
     if (col < q.N && k_cur[i] >= 0) flush(i, col);
   }
 }
 
-// H[s - s_begin][k] = psih(scale_s * 2 pi k / 8192), k < 4096 (fp64, rounded once), the formulas of wavelet_table_kernel
+// H[s - s_begin][k] = psih(scale_s * 2 pi k / F), k < F / 2 (fp64, rounded once), the formulas of wavelet_table_kernel
 __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restrict__ scales, int s_begin, int n_scales,
-                                    int wavelet) {
+                                    int wavelet, int F) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int sl = blockIdx.y;
-  if (sl >= n_scales || k >= 4096) return;
-  const double xi = (double)k * (2.0 * 3.14159265358979323846 / (double)kOsF);
+  if (sl >= n_scales || k >= F / 2) return;
+  const double xi = (double)k * (2.0 * 3.14159265358979323846 / (double)F);
   const double w = scales[s_begin + sl] * xi;
   double v = 0.0;
   if (wavelet == 1) {                                   // "morlet"  cwt.rs:497-520
@@ -235,20 +268,27 @@ __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restr
   } else {                                              // "gmw" | _  cwt.rs:522-542
     if (w > 0.0) v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
   }
-  H[(long long)sl * 4096 + k] = (float)v;
+  H[(long long)sl * (F / 2) + k] = (float)v;
 }
 
-hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, hipStream_t stream) {
+hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
+                               hipStream_t stream) {
   if (n_scales <= 0) return hipSuccess;
-  hipLaunchKernelGGL(cwt_os_table_kernel, dim3(4096 / 256, (unsigned)n_scales), dim3(256), 0, stream, H, d_scales, s_begin,
-                     n_scales, wavelet);
+  const int F = 1024 * rows;
+  hipLaunchKernelGGL(cwt_os_table_kernel, dim3((unsigned)((F / 2 + 255) / 256), (unsigned)n_scales), dim3(256), 0, stream, H,
+                     d_scales, s_begin, n_scales, wavelet, F);
   return hipGetLastError();
 }
 
-hipError_t launch_cwt_os(const CwtOsDev& p, hipStream_t stream) {
+hipError_t launch_cwt_os(const CwtOsDev& p, int rows, hipStream_t stream) {
   if (p.s_end <= p.s_begin) return hipSuccess;
-  const long long tiles = (p.q.N + kOsL - 1) / kOsL;
-  hipLaunchKernelGGL(cwt_os_kernel, dim3((unsigned)tiles), dim3(kOsThreads), 0, stream, p);
+  if (rows == 8) {
+    const long long tiles = (p.q.N + OsCfg<8>::L - 1) / OsCfg<8>::L;
+    hipLaunchKernelGGL(cwt_os_kernel<8>, dim3((unsigned)tiles), dim3(OsCfg<8>::THREADS), 0, stream, p);
+  } else {
+    const long long tiles = (p.q.N + OsCfg<4>::L - 1) / OsCfg<4>::L;
+    hipLaunchKernelGGL(cwt_os_kernel<4>, dim3((unsigned)tiles), dim3(OsCfg<4>::THREADS), 0, stream, p);
+  }
   return hipGetLastError();
 }
 
