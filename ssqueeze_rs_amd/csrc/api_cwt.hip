@@ -52,7 +52,9 @@ struct ssq_cwt_plan {
   int n_cus = 256;
   // time-tiled (overlap-save) ssq path of the short-wavelet scales [os_s0, os_s1) (cwt_os.hip); empty = off
   // [os_s0, os_mid): 4096-point tiles (halo 1024, two blocks per CU); [os_mid, os_s1): 8192-point tiles (halo 2048)
-  int os_s0 = 0, os_mid = 0, os_s1 = 0;
+  // [os_s1, os_d1): 16-fold decimated 8192-point tiles (long wavelets that are band-limited far below Nyquist)
+  int os_s0 = 0, os_mid = 0, os_s1 = 0, os_d1 = 0;
+  void* d_osHd = nullptr;      // [os_d1 - os_s1][4096] psih on the 131072-point grid
   void* d_osH4 = nullptr;      // [os_mid - os_s0][2048] psih on the 4096-point grid
   void* d_osH = nullptr;       // [os_s1 - os_mid][4096] psih on the 8192-point grid
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
@@ -193,8 +195,11 @@ int build_tables(ssq_cwt_plan* pl) {
         if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
       SSQ_HIP(hipMalloc(&pl->d_osH4, sizeof(float) * 2048 * (size_t)(n4 > 0 ? n4 : 1)));
       SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)(n8 > 0 ? n8 : 1)));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH4, pl->d_scales, pl->os_s0, n4, pl->wavelet, 4, nullptr));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_mid, n8, pl->wavelet, 8, nullptr));
+      const int nd = pl->os_d1 - pl->os_s1;
+      SSQ_HIP(hipMalloc(&pl->d_osHd, sizeof(float) * 4096 * (size_t)(nd > 0 ? nd : 1)));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH4, pl->d_scales, pl->os_s0, n4, pl->wavelet, 4, 0, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_mid, n8, pl->wavelet, 8, 0, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHd, pl->d_scales, pl->os_s1, nd, pl->wavelet, 8, kOsLogDec, nullptr));
       SSQ_HIP(hipDeviceSynchronize());
     }
     if (pl->reg && pl->na > 0) {
@@ -250,7 +255,10 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
   if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
   L.os_xs = off;               // time-tiled path: the tiles' spectra
-  if (pl->os_s1 > pl->os_s0) off += align(((pl->N + 2047) / 2048) * 2048LL * 8);   // (either geometry: N rounded up)
+  if (pl->os_s1 > pl->os_s0) {                                 // (any geometry: N rounded up to whole tiles)
+    const long long span = (long long)kOsL << kOsLogDec;
+    off += align(((pl->N + span - 1) / span) * span * 8);
+  }
   L.total = off;
   return L;
 }
@@ -587,7 +595,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     } else if (os) {
       if constexpr (sizeof(T) == 4) {
         // every other scale through the transforms into the workspaces ...
-        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_s0, pl->os_s1)) return rc;
+        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_s0, pl->os_d1)) return rc;
         if (d_dbg_Wx)
           SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
                                  hipMemcpyDeviceToDevice, st));
@@ -613,13 +621,22 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
           o.s_end = rows == 4 ? pl->os_mid : pl->os_s1;
           o.xi_step = (float)((2.0 * M_PI / F) / pl->dt);
           o.inv_F = (float)(1.0 / F);
-          SSQ_HIP(launch_cwt_os(o, rows, st));
+          SSQ_HIP(launch_cwt_os(o, rows, 0, st));
+        }
+        if (pl->os_d1 > pl->os_s1) {
+          const double S = (double)kOsF * (double)(1 << kOsLogDec);
+          o.H = (const float*)pl->d_osHd;
+          o.s_begin = pl->os_s1;
+          o.s_end = pl->os_d1;
+          o.xi_step = (float)((2.0 * M_PI / S) / pl->dt);
+          o.inv_F = (float)(1.0 / S);
+          SSQ_HIP(launch_cwt_os(o, 8, kOsLogDec, st));
         }
         // ... and the rest added by the column-ordered reassignment (read-modify-write)
         q.s_begin = 0;
         q.s_end = pl->os_s0;
         SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
-        q.s_begin = pl->os_s1;
+        q.s_begin = pl->os_d1;
         q.s_end = n;
         SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
       }
@@ -754,6 +771,17 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
           while (mid < best1 && scales[mid] <= 0.5 * a_hi) ++mid;
         if (mid - best0 < 8) mid = best0;
         pl->os_mid = mid;
+        pl->os_d1 = best1;
+        // behind them the long wavelets that are band-limited below 1 / 64 cycles per sample: 16-fold decimated tiles
+        // (halo 16 * 2048 samples; psih_s[k] == 0 from band[s] <= P / 32 on); SSQ_CWT_OS_DEC=0 keeps the transforms
+        const char* ed = std::getenv("SSQ_CWT_OS_DEC");
+        if (!(ed && std::atoi(ed) == 0)) {
+          int d1 = best1;
+          while (d1 < (int)na && scales[d1] <= a_hi * (double)(1 << kOsLogDec) && pl->zoom_logq[(size_t)d1] == 0 &&
+                 (long long)pl->band[(size_t)d1] <= pl->P / 32)
+            ++d1;
+          if (d1 - best1 >= 4) pl->os_d1 = d1;
+        }
       }
     }
   }
@@ -788,6 +816,7 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_tw20);
   hipFree(pl->d_osH);
   hipFree(pl->d_osH4);
+  hipFree(pl->d_osHd);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -838,7 +867,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

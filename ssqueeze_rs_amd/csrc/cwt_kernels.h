@@ -140,6 +140,7 @@ hipError_t launch_cwt_reg_inv(const CwtRegDev& p, int n_cus, hipStream_t stream)
 constexpr int kOsF = 8192;        // rows = 8
 constexpr int kOsL = 4096;
 constexpr int kOsHalo = 2048;     // input samples on either side: the wavelet's time support must fit
+constexpr int kOsLogDec = 4;      // decimated tiles (long, band-limited wavelets): 16-fold, halo 16 * 2048 samples
 struct CwtOsDev {
   const float* x;              // [n_signal] one real signal
   cpx<float>* xs;              // scratch [tiles][F / 2]: the tiles' spectra (k < F / 2)
@@ -155,7 +156,7 @@ struct CwtOsDev {
   float inv_F;                 // 1 / F
 };
 hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
-                               hipStream_t stream);
-hipError_t launch_cwt_os(const CwtOsDev& p, int rows, hipStream_t stream);
+                               int log_dec, hipStream_t stream);
+hipError_t launch_cwt_os(const CwtOsDev& p, int rows, int log_dec, hipStream_t stream);
 
 }  // namespace ssq

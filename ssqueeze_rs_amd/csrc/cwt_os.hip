@@ -62,10 +62,18 @@ __device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
 }  // namespace
 
 // One block = one time tile of OsCfg<R>::L output samples; see the header.
-template <int R>
+// LOGM > 0 (long wavelets that are band-limited below 1 / (4 M) cycles per sample, M = 2^LOGM): the tile works on the
+// M-fold DECIMATED time grid -- F decimated samples span F M original ones, so the halo is M times longer -- and a block
+// computes ONE output phase r of its tile: with S = F M,
+//   Wx[n0 + M m + r] = (1/S) sum_{k < F/2} (X_seg[k] psih(a 2 pi k / S) e^{2 pi i k r / S}) e^{2 pi i k m / F},
+// where X_seg[k], k < F/2, are the low bins of the S-point spectrum of the segment (cwt_os_dec_fwd_kernel: one F-point
+// transform per input phase, summed here).  The M phases of a tile run on the same XCD, so their 8-byte read-modify-
+// writes of neighbouring Tx columns meet in one L2.
+template <int R, int LOGM>
 __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p) {
   using K = OsCfg<R>;
   constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR, H2 = R / 2;
+  constexpr int M = 1 << LOGM;
   __shared__ __attribute__((aligned(16))) cpx<float> zb[2][R * PT];         // kind 0 | kind 1: [row j][column]
   __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
   const int tid = threadIdx.x;
@@ -74,9 +82,20 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   cpx<float>* tw1 = tws;
   cpx<float>* tw2 = tws + 256;
   wave1024_tables(tw1, tw2, p.tw1024, tid, THREADS);
-  const int tile = blockIdx.x;
-  const long long n0 = (long long)tile * L;                    // first output sample (unpadded time)
-  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2);
+  int tile = blockIdx.x, phase = 0;
+  if constexpr (LOGM > 0) {
+    const int bid = blockIdx.x;
+    if (((gridDim.x >> LOGM) & 7) == 0) {                      // blocks x, x + 8, ... share XCD x: a tile's phases together
+      const int j = bid >> 3;
+      tile = (bid & 7) + 8 * (j >> LOGM);
+      phase = j & (M - 1);
+    } else {
+      tile = bid >> LOGM;
+      phase = bid & (M - 1);
+    }
+  }
+  const long long n0 = (long long)tile * ((long long)L << LOGM);   // first output sample of the tile (unpadded time)
+  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2) * M;
   __syncthreads();
 
   // W_F^(c j), j < R, for the columns c = tid + THREADS * u this thread transforms (forward sign): 1, w, w^2 ...
@@ -91,6 +110,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   }
 
   // ---- forward transform of the tile's F input samples: n = 1024 r + c, k = j + R m ----
+  if constexpr (LOGM == 0) {
 #pragma unroll
   for (int u = 0; u < CPT; ++u) {
     const int c = tid + THREADS * u;
@@ -116,6 +136,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   }
   __threadfence_block();
   __syncthreads();                                             // xs of this tile is visible to the whole block (same CU)
+  }
 
   // ---- all eligible scales, ascending ----
   const int kind_w = wv >= R ? 1 : 0;                          // waves 0 .. R-1: Wx rows, R .. 2R-1: dWx rows
@@ -139,8 +160,21 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   for (int u = 0; u < CPT; ++u)
 #pragma unroll
     for (int r = 0; r < H2; ++r) {
-      xk[u][r] = xs[1024 * r + tid + THREADS * u];
-      hk[u][r] = p.H[1024 * r + tid + THREADS * u];
+      const int k = 1024 * r + tid + THREADS * u;
+      if constexpr (LOGM == 0) {
+        xk[u][r] = xs[k];
+      } else {
+        cpx<float> sum = {0.0f, 0.0f};                         // the S-point spectrum's bin k from the M input phases
+        for (int rp = 0; rp < M; ++rp) {
+          const cpx<float> v = xs[(long long)rp * (F / 2) + k];
+          sum.x += v.x;
+          sum.y += v.y;
+        }
+        double sn, cs;                                         // e^{+2 pi i k phase / S}, once per block
+        sincospi(2.0 * (double)k * (double)phase / (double)((long long)F << LOGM), &sn, &cs);
+        xk[u][r] = cmul(sum, cpx<float>{(float)cs, (float)sn});
+      }
+      hk[u][r] = p.H[k];
     }
 #pragma unroll 1
   for (int s = p.s_begin; s < p.s_end; ++s) {
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = HALO + tid + THREADS * i;                   // position inside the F-sample frame
-      const long long col = n0 + tid + THREADS * i;
+      const long long col = n0 + ((long long)(tid + THREADS * i) << LOGM) + phase;
       const cpx<float> Wv = zb[0][(nl & (R - 1)) * PT + (nl >> LOGR)];
       const cpx<float> dW = zb[1][(nl & (R - 1)) * PT + (nl >> LOGR)];
       fl_ptr[i] = nullptr;
@@ -243,18 +277,71 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long col = n0 + tid + THREADS * i;
+    const long long col = n0 + ((long long)(tid + THREADS * i) << LOGM) + phase;
     if (col < q.N && k_cur[i] >= 0) flush(i, col);
+  }
+}
+
+// Decimated tiles, forward part: block (tile, input phase r') transforms the F samples x_seg[M m + r'] and writes
+// e^{-2 pi i k r' / S} * fft_F(...)[k], k < F/2, to xs[tile][r'][k]; the sum over r' is the S-point spectrum's bin k.
+template <int R, int LOGM>
+__global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_dec_fwd_kernel(CwtOsDev p) {
+  using K = OsCfg<R>;
+  constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT;
+  constexpr int M = 1 << LOGM;
+  static_assert(THREADS == 1024, "one column per thread");
+  __shared__ __attribute__((aligned(16))) cpx<float> zb[R * PT];
+  __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
+  const int tid = threadIdx.x;
+  const int t = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cpx<float>* tw1 = tws;
+  cpx<float>* tw2 = tws + 256;
+  wave1024_tables(tw1, tw2, p.tw1024, tid, THREADS);
+  const int tile = blockIdx.x >> LOGM, rp = blockIdx.x & (M - 1);
+  const long long seg0 = (long long)tile * ((long long)L << LOGM) - ((long long)HALO << LOGM);   // segment origin
+  __syncthreads();
+  {
+    cpx<float> wj[R];
+    wj[0] = {1.0f, 0.0f};
+    wj[1] = os_wF<R>(p.tw1024, tid);
+#pragma unroll
+    for (int j = 2; j < R; ++j) wj[j] = cmul(wj[j - 1], wj[1]);
+    cpx<float> v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      v[r] = {load_padded(p.x, seg0 + ((long long)(1024 * r + tid) << LOGM) + rp, p.n_signal, p.padtype), 0.0f};
+    os_dft<R>(v);
+#pragma unroll
+    for (int j = 0; j < R; ++j) zb[j * PT + tid] = cmul(v[j], wj[j]);
+  }
+  __syncthreads();
+  if (wv < R) {
+    cpx<float>* row = zb + wv * PT;
+    cpx<float> v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = row[t + 64 * q];
+    frame_sync<false>();
+    wave1024_front(v, row, t);
+    wave1024_back(v, tw1, tw2, t);
+    cpx<float>* __restrict__ dst = p.xs + ((long long)tile * M + rp) * (F / 2);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = R * (t + 64 * q) + wv;                       // < F / 2
+      double sn, cs;
+      sincospi(-2.0 * (double)k * (double)rp / (double)((long long)F << LOGM), &sn, &cs);
+      dst[k] = cmul(v[q], cpx<float>{(float)cs, (float)sn});
+    }
   }
 }
 
 // H[s - s_begin][k] = psih(scale_s * 2 pi k / F), k < F / 2 (fp64, rounded once), the formulas of wavelet_table_kernel
 __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restrict__ scales, int s_begin, int n_scales,
-                                    int wavelet, int F) {
+                                    int wavelet, int F, int log_dec) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int sl = blockIdx.y;
   if (sl >= n_scales || k >= F / 2) return;
-  const double xi = (double)k * (2.0 * 3.14159265358979323846 / (double)F);
+  const double xi = (double)k * (2.0 * 3.14159265358979323846 / ((double)F * (double)(1 << log_dec)));   // grid of F M points
   const double w = scales[s_begin + sl] * xi;
   double v = 0.0;
   if (wavelet == 1) {                                   // "morlet"  cwt.rs:497-520
@@ -272,22 +359,29 @@ __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restr
 }
 
 hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
-                               hipStream_t stream) {
+                               int log_dec, hipStream_t stream) {
   if (n_scales <= 0) return hipSuccess;
   const int F = 1024 * rows;
   hipLaunchKernelGGL(cwt_os_table_kernel, dim3((unsigned)((F / 2 + 255) / 256), (unsigned)n_scales), dim3(256), 0, stream, H,
-                     d_scales, s_begin, n_scales, wavelet, F);
+                     d_scales, s_begin, n_scales, wavelet, F, log_dec);
   return hipGetLastError();
 }
 
-hipError_t launch_cwt_os(const CwtOsDev& p, int rows, hipStream_t stream) {
+hipError_t launch_cwt_os(const CwtOsDev& p, int rows, int log_dec, hipStream_t stream) {
   if (p.s_end <= p.s_begin) return hipSuccess;
-  if (rows == 8) {
+  if (log_dec == kOsLogDec && rows == 8) {
+    const long long span = (long long)OsCfg<8>::L << kOsLogDec;
+    const long long blocks = ((p.q.N + span - 1) / span) << kOsLogDec;
+    hipLaunchKernelGGL((cwt_os_dec_fwd_kernel<8, kOsLogDec>), dim3((unsigned)blocks), dim3(OsCfg<8>::THREADS), 0, stream, p);
+    hipLaunchKernelGGL((cwt_os_kernel<8, kOsLogDec>), dim3((unsigned)blocks), dim3(OsCfg<8>::THREADS), 0, stream, p);
+  } else if (log_dec != 0) {
+    return hipErrorInvalidValue;
+  } else if (rows == 8) {
     const long long tiles = (p.q.N + OsCfg<8>::L - 1) / OsCfg<8>::L;
-    hipLaunchKernelGGL(cwt_os_kernel<8>, dim3((unsigned)tiles), dim3(OsCfg<8>::THREADS), 0, stream, p);
+    hipLaunchKernelGGL((cwt_os_kernel<8, 0>), dim3((unsigned)tiles), dim3(OsCfg<8>::THREADS), 0, stream, p);
   } else {
     const long long tiles = (p.q.N + OsCfg<4>::L - 1) / OsCfg<4>::L;
-    hipLaunchKernelGGL(cwt_os_kernel<4>, dim3((unsigned)tiles), dim3(OsCfg<4>::THREADS), 0, stream, p);
+    hipLaunchKernelGGL((cwt_os_kernel<4, 0>), dim3((unsigned)tiles), dim3(OsCfg<4>::THREADS), 0, stream, p);
   }
   return hipGetLastError();
 }
