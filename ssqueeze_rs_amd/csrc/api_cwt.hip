@@ -55,6 +55,10 @@ struct ssq_cwt_plan {
   // [os_s1, os_d1): 16-fold decimated 8192-point tiles (long wavelets that are band-limited far below Nyquist)
   int os_s0 = 0, os_mid = 0, os_s1 = 0, os_d1 = 0;
   void* d_osHd = nullptr;      // [os_d1 - os_s1][4096] psih on the 131072-point grid
+  // [os_z0, os_z1): band-limited scales (mode Z's) of plans with P = 2 N by full-circle phase blocks (cwt_os.hip)
+  int os_z0 = 0, os_z1 = 0;
+  void* d_osHz = nullptr;      // [os_z1 - os_z0][2048] psih on the P-point grid
+  std::vector<char> os_mask;   // per scale: 1 = computed by the time-tile family inside ssq_cwt
   void* d_osH4 = nullptr;      // [os_mid - os_s0][2048] psih on the 4096-point grid
   void* d_osH = nullptr;       // [os_s1 - os_mid][4096] psih on the 8192-point grid
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
@@ -189,6 +193,14 @@ int build_tables(ssq_cwt_plan* pl) {
     SSQ_HIP(hipDeviceSynchronize());
   }
   if constexpr (sizeof(T) == 4) {
+    if (pl->os_z1 > pl->os_z0) {
+      const int nz = pl->os_z1 - pl->os_z0;
+      SSQ_HIP(hipMalloc(&pl->d_osHz, sizeof(float) * 2048 * (size_t)nz));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHz, pl->d_scales, pl->os_z0, nz, pl->wavelet, 4, pl->logP - 12, nullptr));
+      SSQ_HIP(hipDeviceSynchronize());
+      if (!pl->reg && !(pl->os_s1 > pl->os_s0))
+        if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
+    }
     if (pl->os_s1 > pl->os_s0) {                               // time-tiled ssq path (any two-step fp32 plan)
       const int n4 = pl->os_mid - pl->os_s0, n8 = pl->os_s1 - pl->os_mid;
       if (!pl->reg)
@@ -354,10 +366,10 @@ int run_forward(const ssq_cwt_plan* pl, CwtDev<T> p, const T* d_x, hipStream_t s
 struct NoAfter {
   int operator()(int, int) const { return 0; }
 };
-// Scales in [skip0, skip1) are left out (the ssq path computes them by time tiles, cwt_os.hip).
+// Scales with skip[s] != 0 are left out (the ssq path computes them by time tiles, cwt_os.hip).
 template <typename T, typename After = NoAfter>
 int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bool l1_norm, bool rpadded,
-                hipStream_t st, After after = After(), int group = 0, int skip0 = 0, int skip1 = 0) {
+                hipStream_t st, After after = After(), int group = 0, const char* skip = nullptr) {
   p.Wx = Wx;
   p.dWx = dWx;
   p.n_kinds = dWx ? 2 : 1;
@@ -391,13 +403,13 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
   // the others through the two-step transform in chunks whose ybuf stays inside the Infinity Cache
   int s0 = 0;
   while (s0 < pl->na) {
-    if (s0 >= skip0 && s0 < skip1) {                       // (only two-step plans reach this loop)
-      s0 = skip1;
+    if (skip && skip[s0]) {                                // (only two-step plans reach this loop)
+      ++s0;
       continue;
     }
     const int lq = pl->zoom_logq[(size_t)s0];
     int s1 = s0 + 1;
-    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq && !(s1 >= skip0 && s1 < skip1)) ++s1;
+    while (s1 < pl->na && pl->zoom_logq[(size_t)s1] == lq && !(skip && skip[s1])) ++s1;
     if (lq > 0) {
       CwtDev<T> z = p;
       z.log_p2 = lq;
@@ -556,7 +568,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   // would not -- profiles/r02_ab_cwt_sweep.txt)
   const char* sweep_env = std::getenv("SSQ_CWT_SWEEP");
   const int sweep_mode = sweep_env ? std::atoi(sweep_env) : 1;
-  const bool os = sizeof(T) == 4 && group == 0 && pl->os_s1 > pl->os_s0;   // short-wavelet scales by time tiles
+  const bool os = sizeof(T) == 4 && group == 0 && (pl->os_s1 > pl->os_s0 || pl->os_z1 > pl->os_z0);   // time-tile family
   const bool sweep = !os && group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
   const bool self_zero = sweep && (sweep_mode == 2 || !pl->can_fuse_ssq());
   const bool side_clear = pl->can_fuse_ssq() && !self_zero;   // clear Tx beside the transforms
@@ -595,7 +607,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     } else if (os) {
       if constexpr (sizeof(T) == 4) {
         // every other scale through the transforms into the workspaces ...
-        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_s0, pl->os_d1)) return rc;
+        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_mask.data())) return rc;
         if (d_dbg_Wx)
           SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
                                  hipMemcpyDeviceToDevice, st));
@@ -632,13 +644,29 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
           o.inv_F = (float)(1.0 / S);
           SSQ_HIP(launch_cwt_os(o, 8, kOsLogDec, st));
         }
-        // ... and the rest added by the column-ordered reassignment (read-modify-write)
-        q.s_begin = 0;
-        q.s_end = pl->os_s0;
-        SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
-        q.s_begin = pl->os_d1;
-        q.s_end = n;
-        SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
+        if (pl->os_z1 > pl->os_z0) {                             // band-limited scales: full-circle phase blocks
+          o.H = (const float*)pl->d_osHz;
+          o.xh = p.xh;
+          o.log_dec = pl->logP - 12;
+          o.s_begin = pl->os_z0;
+          o.s_end = pl->os_z1;
+          o.xi_step = (float)((2.0 * M_PI / (double)pl->P) / pl->dt);
+          o.inv_F = (float)(1.0 / (double)pl->P);
+          SSQ_HIP(launch_cwt_os_full(o, st));
+        }
+        // ... and the rest added by the column-ordered reassignment (read-modify-write), run by run
+        for (int s0 = 0; s0 < n;) {
+          if (pl->os_mask[(size_t)s0]) {
+            ++s0;
+            continue;
+          }
+          int s1 = s0;
+          while (s1 < n && !pl->os_mask[(size_t)s1]) ++s1;
+          q.s_begin = s0;
+          q.s_end = s1;
+          SSQ_HIP(launch_cwt_reassign<T>(q, st, false));
+          s0 = s1;
+        }
       }
       continue;
     } else {
@@ -785,6 +813,28 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       }
     }
   }
+  // full-circle phase blocks for the band-limited scales: P = 2 N (the kept samples are the middle half of the padded
+  // length), spectrum below 2048 bins; SSQ_CWT_OS_FULL=0 keeps mode Z + the column reassignment for them
+  {
+    const char* e = std::getenv("SSQ_CWT_OS");
+    const char* ef = std::getenv("SSQ_CWT_OS_FULL");
+    if (dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0) && !(ef && std::atoi(ef) == 0) &&
+        pl->P == 2 * pl->N && n_signal >= 64LL * kOsL) {
+      bool ascending = true;
+      for (int64_t i = 1; i < na; ++i) ascending = ascending && scales[i] >= scales[i - 1];
+      int z0 = pl->os_d1;
+      while (ascending && z0 < (int)na && !(pl->zoom_logq[(size_t)z0] > 0 && pl->band[(size_t)z0] <= 2048)) ++z0;
+      int z1 = z0;
+      while (ascending && z1 < (int)na && pl->zoom_logq[(size_t)z1] > 0 && pl->band[(size_t)z1] <= 2048) ++z1;
+      if (z1 - z0 >= 8) {
+        pl->os_z0 = z0;
+        pl->os_z1 = z1;
+      }
+    }
+    pl->os_mask.assign((size_t)(na > 0 ? na : 1), 0);
+    for (int i = pl->os_s0; i < pl->os_d1; ++i) pl->os_mask[(size_t)i] = 1;
+    for (int i = pl->os_z0; i < pl->os_z1; ++i) pl->os_mask[(size_t)i] = 1;
+  }
   int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
   if (rc) {
     ssq_cwt_plan_destroy(pl);
@@ -817,6 +867,7 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_osH);
   hipFree(pl->d_osH4);
   hipFree(pl->d_osHd);
+  hipFree(pl->d_osHz);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -867,7 +918,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC", "SSQ_CWT_OS_FULL"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

@@ -144,6 +144,8 @@ constexpr int kOsLogDec = 4;      // decimated tiles (long, band-limited wavelet
 struct CwtOsDev {
   const float* x;              // [n_signal] one real signal
   cpx<float>* xs;              // scratch [tiles][F / 2]: the tiles' spectra (k < F / 2)
+  const cpx<float>* xh;        // full-circle mode: the padded signal's spectrum in natural order
+  int log_dec;                 // full-circle mode: log2(P / 4096)
   const float* H;              // [s_end - s_begin][F / 2] psih(scale * 2 pi k / F)
   const cpx<float>* tw1024;    // W_1024^j
   CwtSsqDev<float> q;          // binning parameters, Tx (zero or partial sums on entry), optional (w, k) hook
@@ -158,5 +160,8 @@ struct CwtOsDev {
 hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
                                int log_dec, hipStream_t stream);
 hipError_t launch_cwt_os(const CwtOsDev& p, int rows, int log_dec, hipStream_t stream);
+// band-limited scales (spectrum below 2048 bins) of plans with P = 2 N: one output phase per block over the whole padded
+// signal (4096-point transforms on the P / 4096-fold decimated grid), bins and run merge on chip
+hipError_t launch_cwt_os_full(const CwtOsDev& p, hipStream_t stream);
 
 }  // namespace ssq

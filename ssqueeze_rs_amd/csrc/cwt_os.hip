@@ -69,11 +69,17 @@ __device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
 // where X_seg[k], k < F/2, are the low bins of the S-point spectrum of the segment (cwt_os_dec_fwd_kernel: one F-point
 // transform per input phase, summed here).  The M phases of a tile run on the same XCD, so their 8-byte read-modify-
 // writes of neighbouring Tx columns meet in one L2.
+// LOGM < 0 (FULL circle, decimation 2^p.log_dec chosen at run time with S = F M = the padded length P, for P = 2 N):
+// the "segment" is the whole padded signal, so the circular convolution is the reference's own, exact for every scale
+// whose spectrum ends below F / 2 bins -- the band-limited scales of mode Z -- and X_seg is simply the spectrum xh the
+// forward transform of the call has left in natural order; ONE tile, P / F phases = blocks.
 template <int R, int LOGM>
 __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p) {
   using K = OsCfg<R>;
   constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR, H2 = R / 2;
-  constexpr int M = 1 << LOGM;
+  constexpr bool FULL = LOGM < 0;
+  const int logm = FULL ? p.log_dec : LOGM;                    // (a compile-time constant unless FULL)
+  const int M = 1 << logm;
   __shared__ __attribute__((aligned(16))) cpx<float> zb[2][R * PT];         // kind 0 | kind 1: [row j][column]
   __shared__ __attribute__((aligned(16))) cpx<float> tws[kWave1024TwElems];
   const int tid = threadIdx.x;
@@ -83,7 +89,11 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   cpx<float>* tw2 = tws + 256;
   wave1024_tables(tw1, tw2, p.tw1024, tid, THREADS);
   int tile = blockIdx.x, phase = 0;
-  if constexpr (LOGM > 0) {
+  if constexpr (FULL) {
+    const int bid = blockIdx.x;                                // gridDim.x = M, a multiple of 8: XCD x takes M / 8
+    tile = 0;                                                  // neighbouring phases = neighbouring Tx columns
+    phase = (bid & 7) * (M >> 3) + (bid >> 3);
+  } else if constexpr (LOGM > 0) {
     const int bid = blockIdx.x;
     if (((gridDim.x >> LOGM) & 7) == 0) {                      // blocks x, x + 8, ... share XCD x: a tile's phases together
       const int j = bid >> 3;
@@ -94,8 +104,8 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
       phase = bid & (M - 1);
     }
   }
-  const long long n0 = (long long)tile * ((long long)L << LOGM);   // first output sample of the tile (unpadded time)
-  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2) * M;
+  const long long n0 = (long long)tile * ((long long)L << logm);   // first output sample of the tile (unpadded time)
+  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2) * M;   // (unused when FULL)
   __syncthreads();
 
   // W_F^(c j), j < R, for the columns c = tid + THREADS * u this thread transforms (forward sign): 1, w, w^2 ...
@@ -164,14 +174,18 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
       if constexpr (LOGM == 0) {
         xk[u][r] = xs[k];
       } else {
-        cpx<float> sum = {0.0f, 0.0f};                         // the S-point spectrum's bin k from the M input phases
-        for (int rp = 0; rp < M; ++rp) {
-          const cpx<float> v = xs[(long long)rp * (F / 2) + k];
-          sum.x += v.x;
-          sum.y += v.y;
+        cpx<float> sum = {0.0f, 0.0f};
+        if constexpr (FULL) {
+          sum = p.xh[k];                                         // the padded signal's own spectrum
+        } else {
+          for (int rp = 0; rp < M; ++rp) {                       // the S-point spectrum's bin k from the M input phases
+            const cpx<float> v = xs[(long long)rp * (F / 2) + k];
+            sum.x += v.x;
+            sum.y += v.y;
+          }
         }
         double sn, cs;                                         // e^{+2 pi i k phase / S}, once per block
-        sincospi(2.0 * (double)k * (double)phase / (double)((long long)F << LOGM), &sn, &cs);
+        sincospi(2.0 * (double)k * (double)phase / (double)((long long)F << logm), &sn, &cs);
         xk[u][r] = cmul(sum, cpx<float>{(float)cs, (float)sn});
       }
       hk[u][r] = p.H[k];
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = HALO + tid + THREADS * i;                   // position inside the F-sample frame
-      const long long col = n0 + ((long long)(tid + THREADS * i) << LOGM) + phase;
+      const long long col = n0 + ((long long)(tid + THREADS * i) << logm) + phase;
       const cpx<float> Wv = zb[0][(nl & (R - 1)) * PT + (nl >> LOGR)];
       const cpx<float> dW = zb[1][(nl & (R - 1)) * PT + (nl >> LOGR)];
       fl_ptr[i] = nullptr;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long col = n0 + ((long long)(tid + THREADS * i) << LOGM) + phase;
+    const long long col = n0 + ((long long)(tid + THREADS * i) << logm) + phase;
     if (col < q.N && k_cur[i] >= 0) flush(i, col);
   }
 }
@@ -364,6 +378,13 @@ hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, in
   const int F = 1024 * rows;
   hipLaunchKernelGGL(cwt_os_table_kernel, dim3((unsigned)((F / 2 + 255) / 256), (unsigned)n_scales), dim3(256), 0, stream, H,
                      d_scales, s_begin, n_scales, wavelet, F, log_dec);
+  return hipGetLastError();
+}
+
+hipError_t launch_cwt_os_full(const CwtOsDev& p, hipStream_t stream) {
+  if (p.s_end <= p.s_begin) return hipSuccess;
+  if (p.log_dec < 3 || !p.xh) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((cwt_os_kernel<4, -1>), dim3(1u << p.log_dec), dim3(OsCfg<4>::THREADS), 0, stream, p);
   return hipGetLastError();
 }
 
