@@ -415,3 +415,29 @@ def test_ssq_cwt_time_tiled_batch_equals_single_signals():
         Tx, f = _rs.ssq_cwt(xb[i], wavelet="morlet", scales=scales)
         assert np.array_equal(f, fb) and np.array_equal(Tx, Txb[i]), i
     assert np.count_nonzero(Txb[1]) > 0
+
+
+@pytest.mark.parametrize("opts", [
+    dict(squeezing="lebesgue", flipud=False),
+    dict(fs=50.0, gamma=1e-3, maprange="maximal"),
+    dict(padtype="zero", ssq_freqs="linear"),
+])
+def test_ssq_cwt_time_tiled_options(opts, monkeypatch):
+    """The time-tile family takes the same options as the frequency-domain path (lebesgue weights, no flip, a sampling
+    rate, a threshold, the other frequency maps, zero padding): Tx against SSQ_CWT_OS=0 by column sums and row energies,
+    the same bins for all but a handful of elements.  N = 2^19: plain, decimated and full-circle tiles all run."""
+    N = 1 << 19
+    x = _sig(N, 61, np.float32)
+    scales = 2.0 ** np.linspace(1.0, 18.0, 48)
+    Tx, f, dbg = _rs.ssq_cwt(x, wavelet="morlet", scales=scales, _debug=True, **opts)
+    monkeypatch.setenv("SSQ_CWT_OS", "0")
+    Tx0, f0, dbg0 = _rs.ssq_cwt(x, wavelet="morlet", scales=scales, _debug=True, **opts)
+    assert np.array_equal(f, f0)
+    assert sum(not np.array_equal(dbg["Wx"][i], dbg0["Wx"][i]) for i in range(48)) >= 20
+    assert (dbg["k"] == dbg0["k"]).mean() >= 0.999
+    cs, cs0 = Tx.astype(np.complex128).sum(0), Tx0.astype(np.complex128).sum(0)
+    # (a column may differ by whole elements whose keep / bin decision sits on a threshold: with lebesgue weights one such
+    # element moves a column sum by 1 / na)
+    assert (np.abs(cs - cs0) > 1e-3 * np.abs(cs0).max()).mean() <= 2e-3
+    re, re0 = (np.abs(Tx.astype(np.complex128)) ** 2).sum(1), (np.abs(Tx0.astype(np.complex128)) ** 2).sum(1)
+    assert np.abs(re - re0).max() <= 2e-3 * re0.max()
