@@ -615,6 +615,16 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
           SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_dWx + b * plane, dW, (size_t)plane * sizeof(cpx<T>),
                                  hipMemcpyDeviceToDevice, st));
         SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));           // Tx is clear from here on
+        // the scales in FRONT of the tiled ones first, while Tx is still empty: with the written-rows bitmap their runs
+        // are plain stores (behind the tile kernels each would be a dependent read-modify-write chain per column)
+        int lead = 0;
+        while (lead < n && !pl->os_mask[(size_t)lead]) ++lead;
+        const bool lead_sweep = lead > 0 && lead < n && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
+        if (lead_sweep) {
+          q.s_begin = 0;
+          q.s_end = lead;
+          SSQ_HIP(launch_cwt_reassign_sweep<T>(q, st, false));
+        }
         // ... the short-wavelet scales tile by tile straight into Tx (their Wx / dWx exist only on chip) ...
         CwtOsDev o;
         std::memset(&o, 0, sizeof(o));
@@ -655,7 +665,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
           SSQ_HIP(launch_cwt_os_full(o, st));
         }
         // ... and the rest added by the column-ordered reassignment (read-modify-write), run by run
-        for (int s0 = 0; s0 < n;) {
+        for (int s0 = lead_sweep ? lead : 0; s0 < n;) {
           if (pl->os_mask[(size_t)s0]) {
             ++s0;
             continue;

@@ -850,18 +850,18 @@ __global__ void cwt_reassign_sweep_kernel(CwtSsqDev<T> p) {
   };
   int k_cur = -1;
   cpx<T> acc = {(T)0, (T)0};
-  for (int i0 = 0; i0 < p.na; i0 += UN) {
+  for (int i0 = p.s_begin; i0 < p.s_end; i0 += UN) {     // (the scales [s_begin, s_end); the bitmap spans all na rows)
     cpx<T> Wb[UN], dWb[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int ii = (i0 + u < p.na) ? i0 + u : p.na - 1;
+      const int ii = (i0 + u < p.s_end) ? i0 + u : p.s_end - 1;
       Wb[u] = Wxp[(long long)ii * p.N];
       dWb[u] = dWxp[(long long)ii * p.N];
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int i = i0 + u;
-      if (i >= p.na) break;
+      if (i >= p.s_end) break;
       const cpx<T> Wv = Wb[u];
       T w;
       const int kk = reassign_bin(p, Wv, dWb[u], w);
@@ -898,6 +898,7 @@ bool cwt_reassign_can_sweep(int na) {
 }
 template <typename T>
 hipError_t launch_cwt_reassign_sweep(const CwtSsqDev<T>& p, hipStream_t stream, bool zero_fill) {
+  if (p.s_end <= p.s_begin && !zero_fill) return hipSuccess;
   const size_t lds = (size_t)((p.na + 31) / 32) * 64 * sizeof(unsigned);
   const dim3 grid((unsigned)((p.N + 63) / 64));
   if (zero_fill) hipLaunchKernelGGL((cwt_reassign_sweep_kernel<T, true>), grid, dim3(64), lds, stream, p);
