@@ -58,6 +58,13 @@ struct ssq_cwt_plan {
   // [os_z0, os_z1): band-limited scales (mode Z's) of plans with P = 2 N by full-circle phase blocks (cwt_os.hip)
   int os_z0 = 0, os_z1 = 0;
   void* d_osHz = nullptr;      // [os_z1 - os_z0][2048] psih on the P-point grid
+  // [os_a0, os_s0): the finest scales on tiles of the ANALYTIC signal (wavelet spectrum continued beyond Nyquist)
+  int os_a0 = 0;
+  void* d_osHa = nullptr;      // [os_s0 - os_a0][4096] psih on the 4096-point grid, all bins
+  void* d_xa_psiT = nullptr;   // the pseudo-scale "1 for k <= P/2" in the register-core layout (xa = ifft of X times it)
+  long long* d_xa_off = nullptr;   // its one-entry tables: psiT_off, psi_off | A, band | 1/P
+  int* d_xa_int = nullptr;
+  float* d_xa_scale = nullptr;
   std::vector<char> os_mask;   // per scale: 1 = computed by the time-tile family inside ssq_cwt
   void* d_osH4 = nullptr;      // [os_mid - os_s0][2048] psih on the 4096-point grid
   void* d_osH = nullptr;       // [os_s1 - os_mid][4096] psih on the 8192-point grid
@@ -193,10 +200,33 @@ int build_tables(ssq_cwt_plan* pl) {
     SSQ_HIP(hipDeviceSynchronize());
   }
   if constexpr (sizeof(T) == 4) {
+    if (pl->os_s0 > pl->os_a0) {                               // analytic-input tiles (register-core plans only)
+      const int nA = pl->os_s0 - pl->os_a0;
+      SSQ_HIP(hipMalloc(&pl->d_osHa, sizeof(float) * 4096 * (size_t)nA));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHa, pl->d_scales, pl->os_a0, nA, pl->wavelet, 4, 0, true, nullptr));
+      const long long half = pl->P / 2;
+      const long long bnd = half + 1 < (1LL << 20) ? half + 1 : (1LL << 20);
+      const int A = (int)((bnd + 1023) / 1024);
+      std::vector<float> ones((size_t)A * 1024);
+      for (int b = 0; b < 1024; ++b)
+        for (int aa = 0; aa < A; ++aa) ones[(size_t)b * A + aa] = (1024LL * aa + b <= half) ? 1.0f : 0.0f;
+      SSQ_HIP(hipMalloc(&pl->d_xa_psiT, sizeof(float) * ones.size()));
+      SSQ_HIP(hipMemcpy(pl->d_xa_psiT, ones.data(), sizeof(float) * ones.size(), hipMemcpyHostToDevice));
+      const long long offs[2] = {0, -half};                    // psiT_off | psi_off: psih[psi_off + P/2] = entry 0 = 1
+      const int ints[2] = {A, (int)(half + 1)};                // A | band
+      const float sc = (float)(1.0 / (double)pl->P);
+      SSQ_HIP(hipMalloc((void**)&pl->d_xa_off, sizeof(offs)));
+      SSQ_HIP(hipMalloc((void**)&pl->d_xa_int, sizeof(ints)));
+      SSQ_HIP(hipMalloc((void**)&pl->d_xa_scale, sizeof(float)));
+      SSQ_HIP(hipMemcpy(pl->d_xa_off, offs, sizeof(offs), hipMemcpyHostToDevice));
+      SSQ_HIP(hipMemcpy(pl->d_xa_int, ints, sizeof(ints), hipMemcpyHostToDevice));
+      SSQ_HIP(hipMemcpy(pl->d_xa_scale, &sc, sizeof(float), hipMemcpyHostToDevice));
+      SSQ_HIP(hipDeviceSynchronize());
+    }
     if (pl->os_z1 > pl->os_z0) {
       const int nz = pl->os_z1 - pl->os_z0;
       SSQ_HIP(hipMalloc(&pl->d_osHz, sizeof(float) * 2048 * (size_t)nz));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHz, pl->d_scales, pl->os_z0, nz, pl->wavelet, 4, pl->logP - 12, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHz, pl->d_scales, pl->os_z0, nz, pl->wavelet, 4, pl->logP - 12, false, nullptr));
       SSQ_HIP(hipDeviceSynchronize());
       if (!pl->reg && !(pl->os_s1 > pl->os_s0))
         if (int rc = upload_tw<float>(&pl->d_tw1024, 1024, 1024, 1)) return rc;
@@ -209,9 +239,9 @@ int build_tables(ssq_cwt_plan* pl) {
       SSQ_HIP(hipMalloc(&pl->d_osH, sizeof(float) * 4096 * (size_t)(n8 > 0 ? n8 : 1)));
       const int nd = pl->os_d1 - pl->os_s1;
       SSQ_HIP(hipMalloc(&pl->d_osHd, sizeof(float) * 4096 * (size_t)(nd > 0 ? nd : 1)));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH4, pl->d_scales, pl->os_s0, n4, pl->wavelet, 4, 0, nullptr));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_mid, n8, pl->wavelet, 8, 0, nullptr));
-      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHd, pl->d_scales, pl->os_s1, nd, pl->wavelet, 8, kOsLogDec, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH4, pl->d_scales, pl->os_s0, n4, pl->wavelet, 4, 0, false, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osH, pl->d_scales, pl->os_mid, n8, pl->wavelet, 8, 0, false, nullptr));
+      SSQ_HIP(launch_cwt_os_table((float*)pl->d_osHd, pl->d_scales, pl->os_s1, nd, pl->wavelet, 8, kOsLogDec, false, nullptr));
       SSQ_HIP(hipDeviceSynchronize());
     }
     if (pl->reg && pl->na > 0) {
@@ -248,7 +278,7 @@ int build_tables(ssq_cwt_plan* pl) {
 }
 
 struct WsLayout {
-  long long xh = 0, ybuf = 0, w = 0, dw = 0, xc = 0, os_xs = 0, total = 0;
+  long long xh = 0, ybuf = 0, w = 0, dw = 0, xc = 0, os_xs = 0, xa = 0, total = 0;
 };
 WsLayout ws_layout(const ssq_cwt_plan* pl) {
   const long long csz = pl->dtype == SSQ_F32 ? 8 : 16;
@@ -267,10 +297,12 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
   if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
   L.os_xs = off;               // time-tiled path: the tiles' spectra
-  if (pl->os_s1 > pl->os_s0) {                                 // (any geometry: N rounded up to whole tiles)
-    const long long span = (long long)kOsL << kOsLogDec;
-    off += align(((pl->N + span - 1) / span) * span * 8);
+  if (pl->os_s1 > pl->os_s0) {                                 // (any geometry: N rounded up to whole tiles; the
+    const long long span = (long long)kOsL << kOsLogDec;       //  analytic-input tiles keep all F bins: twice)
+    off += align(((pl->N + span - 1) / span) * span * 8 * (pl->os_s0 > pl->os_a0 ? 2 : 1));
   }
+  L.xa = off;                  // the analytic signal on the padded grid
+  if (pl->os_s0 > pl->os_a0) off += align(pl->P * 8);
   L.total = off;
   return L;
 }
@@ -636,6 +668,34 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
         o.dbg_dWx = d_dbg_dWx ? (cpx<float>*)d_dbg_dWx + b * plane : nullptr;
         o.n_signal = pl->N;
         o.padtype = pl->padtype;
+        if (pl->os_s0 > pl->os_a0) {
+          // the analytic signal xa = ifft_P(X 1[k <= P/2]): the register-core transform of the pseudo-scale "one"
+          CwtDev<T> pa = p;
+          pa.scale0 = 0;
+          pa.n_kinds = 1;
+          pa.n_transforms = 1;
+          pa.rpadded = 1;
+          pa.cols = pl->P;
+          CwtRegDev r = reg_dev<T>(pl, pa);
+          r.psiT = (const float*)pl->d_xa_psiT;
+          r.psiT_off = pl->d_xa_off;
+          r.psiT_A = pl->d_xa_int;
+          r.band = pl->d_xa_int + 1;
+          r.psih = (const float*)pl->d_xa_psiT;
+          r.psi_off = pl->d_xa_off + 1;
+          r.out_scale = pl->d_xa_scale;
+          r.Wx = (cpx<float>*)(ws + L.xa);
+          r.dWx = nullptr;
+          SSQ_HIP(launch_cwt_reg_inv(r, pl->n_cus, st));
+          o.xa = (const cpx<float>*)(ws + L.xa);
+          o.xa_off = pl->n1;
+          o.H = (const float*)pl->d_osHa;
+          o.s_begin = pl->os_a0;
+          o.s_end = pl->os_s0;
+          o.xi_step = (float)((2.0 * M_PI / 4096.0) / pl->dt);
+          o.inv_F = (float)(1.0 / 4096.0);
+          SSQ_HIP(launch_cwt_os_analytic(o, st));
+        }
         for (int rows = 4; rows <= 8; rows += 4) {               // ascending scales: the short tiles first
           const double F = 1024.0 * rows;
           o.H = (const float*)(rows == 4 ? pl->d_osH4 : pl->d_osH);
@@ -820,6 +880,17 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
             ++d1;
           if (d1 - best1 >= 4) pl->os_d1 = d1;
         }
+        // in front of them the finest scales, whose psih is NOT negligible at Nyquist, on tiles of the analytic signal
+        // (register-core plans compute it with one extra transform); the continued spectrum must vanish by 2 pi:
+        // Morlet a >= 1.97, GMW a >= 0.64.  SSQ_CWT_OS_ANALYTIC=0 keeps the register-core transforms for them
+        const char* ea = std::getenv("SSQ_CWT_OS_ANALYTIC");
+        pl->os_a0 = best0;
+        if (pl->reg && !(ea && std::atoi(ea) == 0)) {
+          const double a_ext = wavelet == SSQ_WAVELET_MORLET ? 1.97 : 0.64;
+          int a0 = best0;
+          while (a0 > 0 && scales[a0 - 1] >= a_ext && pl->zoom_logq[(size_t)(a0 - 1)] == 0) --a0;
+          pl->os_a0 = a0;
+        }
       }
     }
   }
@@ -842,7 +913,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       }
     }
     pl->os_mask.assign((size_t)(na > 0 ? na : 1), 0);
-    for (int i = pl->os_s0; i < pl->os_d1; ++i) pl->os_mask[(size_t)i] = 1;
+    for (int i = (pl->os_s1 > pl->os_s0 ? pl->os_a0 : 0); i < pl->os_d1; ++i) pl->os_mask[(size_t)i] = 1;
     for (int i = pl->os_z0; i < pl->os_z1; ++i) pl->os_mask[(size_t)i] = 1;
   }
   int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
@@ -878,6 +949,11 @@ int ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
   hipFree(pl->d_osH4);
   hipFree(pl->d_osHd);
   hipFree(pl->d_osHz);
+  hipFree(pl->d_osHa);
+  hipFree(pl->d_xa_psiT);
+  hipFree(pl->d_xa_off);
+  hipFree(pl->d_xa_int);
+  hipFree(pl->d_xa_scale);
   if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   if (pl->ev_join) (void)hipEventDestroy(pl->ev_join);
   if (pl->side) (void)hipStreamDestroy(pl->side);
@@ -928,7 +1004,7 @@ namespace {
 // the switches plan creation reads from the environment are part of the key (tests flip them between calls)
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC", "SSQ_CWT_OS_FULL"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC", "SSQ_CWT_OS_FULL", "SSQ_CWT_OS_ANALYTIC"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

@@ -73,10 +73,18 @@ __device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
 // the "segment" is the whole padded signal, so the circular convolution is the reference's own, exact for every scale
 // whose spectrum ends below F / 2 bins -- the band-limited scales of mode Z -- and X_seg is simply the spectrum xh the
 // forward transform of the call has left in natural order; ONE tile, P / F phases = blocks.
-template <int R, int LOGM>
+// CPLX (plain tiles only): the input is the ANALYTIC signal xa = ifft_P(X 1[k <= P/2]) of the padded signal (complex, one
+// extra inverse transform per call) and the wavelet's spectrum is continued smoothly beyond the Nyquist frequency
+// (psih(a w) for w up to 2 pi, all F bins live).  The reference zeroes the negative frequencies of X psih; with xa as
+// the input that cut is already in the signal, the filter stays smooth -- hence short in time -- and the finest scales,
+// whose psih is NOT negligible at Nyquist, become tile-able as well.
+template <int R, int LOGM, bool CPLX = false>
 __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p) {
   using K = OsCfg<R>;
-  constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR, H2 = R / 2;
+  constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR;
+  constexpr int H2 = CPLX ? R : R / 2;                         // live rows of the spectrum
+  constexpr int NS = CPLX ? F : F / 2;                         // spectrum bins kept per tile / wavelet row
+  static_assert(!CPLX || LOGM == 0, "analytic input: plain tiles");
   constexpr bool FULL = LOGM < 0;
   const int logm = FULL ? p.log_dec : LOGM;                    // (a compile-time constant unless FULL)
   const int M = 1 << logm;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
     }
   }
   const long long n0 = (long long)tile * ((long long)L << logm);   // first output sample of the tile (unpadded time)
-  cpx<float>* __restrict__ xs = p.xs + (long long)tile * (F / 2) * M;   // (unused when FULL)
+  cpx<float>* __restrict__ xs = p.xs + (long long)tile * NS * M;        // (unused when FULL)
   __syncthreads();
 
   // W_F^(c j), j < R, for the columns c = tid + THREADS * u this thread transforms (forward sign): 1, w, w^2 ...
@@ -126,7 +134,10 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
     const int c = tid + THREADS * u;
     cpx<float> v[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = {load_padded(p.x, n0 - HALO + 1024 * r + c, p.n_signal, p.padtype), 0.0f};
+    for (int r = 0; r < R; ++r) {
+      if constexpr (CPLX) v[r] = p.xa[p.xa_off + n0 - HALO + 1024 * r + c];
+      else v[r] = {load_padded(p.x, n0 - HALO + 1024 * r + c, p.n_signal, p.padtype), 0.0f};
+    }
     os_dft<R>(v);
 #pragma unroll
     for (int j = 0; j < R; ++j) zb[0][j * PT + c] = cmul(v[j], wj[u][j]);
@@ -140,9 +151,9 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
     frame_sync<false>();
     wave1024_front(v, row, t);
     wave1024_back(v, tw1, tw2, t);
-    // X[k = wv + R m], m = t + 64 q; only k < F / 2 is used: m < 512
+    // X[k = wv + R m], m = t + 64 q; only k < NS is used: m < NS / R
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xs[R * (t + 64 * q) + wv] = v[q];
+    for (int q = 0; q < (CPLX ? 16 : 8); ++q) xs[R * (t + 64 * q) + wv] = v[q];
   }
   __threadfence_block();
   __syncthreads();                                             // xs of this tile is visible to the whole block (same CU)
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
           sum = p.xh[k];                                         // the padded signal's own spectrum
         } else {
           for (int rp = 0; rp < M; ++rp) {                       // the S-point spectrum's bin k from the M input phases
-            const cpx<float> v = xs[(long long)rp * (F / 2) + k];
+            const cpx<float> v = xs[(long long)rp * NS + k];
             sum.x += v.x;
             sum.y += v.y;
           }
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
       frame_sync<false>();
       wave1024_front(v, myrow, t);
       if (s + 1 < p.s_end) {
-        const float* __restrict__ Hn = p.H + (long long)(s + 1 - p.s_begin) * (F / 2);
+        const float* __restrict__ Hn = p.H + (long long)(s + 1 - p.s_begin) * NS;
 #pragma unroll
         for (int u = 0; u < CPT; ++u)
 #pragma unroll
@@ -351,10 +362,10 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_dec_fwd_kernel(Cw
 
 // H[s - s_begin][k] = psih(scale_s * 2 pi k / F), k < F / 2 (fp64, rounded once), the formulas of wavelet_table_kernel
 __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restrict__ scales, int s_begin, int n_scales,
-                                    int wavelet, int F, int log_dec) {
+                                    int wavelet, int F, int log_dec, int entries) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int sl = blockIdx.y;
-  if (sl >= n_scales || k >= F / 2) return;
+  if (sl >= n_scales || k >= entries) return;
   const double xi = (double)k * (2.0 * 3.14159265358979323846 / ((double)F * (double)(1 << log_dec)));   // grid of F M points
   const double w = scales[s_begin + sl] * xi;
   double v = 0.0;
@@ -369,15 +380,24 @@ __global__ void cwt_os_table_kernel(float* __restrict__ H, const double* __restr
   } else {                                              // "gmw" | _  cwt.rs:522-542
     if (w > 0.0) v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
   }
-  H[(long long)sl * (F / 2) + k] = (float)v;
+  H[(long long)sl * entries + k] = (float)v;
 }
 
 hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, int n_scales, int wavelet, int rows,
-                               int log_dec, hipStream_t stream) {
+                               int log_dec, bool all_bins, hipStream_t stream) {
   if (n_scales <= 0) return hipSuccess;
   const int F = 1024 * rows;
-  hipLaunchKernelGGL(cwt_os_table_kernel, dim3((unsigned)((F / 2 + 255) / 256), (unsigned)n_scales), dim3(256), 0, stream, H,
-                     d_scales, s_begin, n_scales, wavelet, F, log_dec);
+  const int entries = all_bins ? F : F / 2;                    // all_bins: continued beyond Nyquist (analytic-input tiles)
+  hipLaunchKernelGGL(cwt_os_table_kernel, dim3((unsigned)((entries + 255) / 256), (unsigned)n_scales), dim3(256), 0, stream, H,
+                     d_scales, s_begin, n_scales, wavelet, F, log_dec, entries);
+  return hipGetLastError();
+}
+
+hipError_t launch_cwt_os_analytic(const CwtOsDev& p, hipStream_t stream) {
+  if (p.s_end <= p.s_begin) return hipSuccess;
+  if (!p.xa) return hipErrorInvalidValue;
+  const long long tiles = (p.q.N + OsCfg<4>::L - 1) / OsCfg<4>::L;
+  hipLaunchKernelGGL((cwt_os_kernel<4, 0, true>), dim3((unsigned)tiles), dim3(OsCfg<4>::THREADS), 0, stream, p);
   return hipGetLastError();
 }
 
