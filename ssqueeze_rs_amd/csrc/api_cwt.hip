@@ -66,6 +66,7 @@ struct ssq_cwt_plan {
   int* d_xa_int = nullptr;
   float* d_xa_scale = nullptr;
   std::vector<char> os_mask;   // per scale: 1 = computed by the time-tile family inside ssq_cwt
+  bool all_tiled = false;      // every scale is: the ssq path needs no Wx / dWx workspaces at all
   void* d_osH4 = nullptr;      // [os_mid - os_s0][2048] psih on the 4096-point grid
   void* d_osH = nullptr;       // [os_s1 - os_mid][4096] psih on the 8192-point grid
   // ssq path of two-step plans: Tx is cleared on a side stream while the transforms run
@@ -290,10 +291,10 @@ WsLayout ws_layout(const ssq_cwt_plan* pl) {
   L.ybuf = off;
   off += align(pl->big ? 2LL * pl->chunk * 2 * pl->P * csz              // spectra of a chunk + the FFT's ping-pong half
                        : (pl->two_step ? (long long)pl->chunk * 2 * pl->P * csz : 0));
-  L.w = off;
-  off += align((long long)pl->na * pl->N * csz);
+  L.w = off;                   // (all scales time-tiled: Wx / dWx never exist in memory, nothing is reserved)
+  if (!pl->all_tiled) off += align((long long)pl->na * pl->N * csz);
   L.dw = off;                  // fused ssq path: the 16-bit row indices K live here instead of dWx
-  off += align((long long)pl->na * pl->N * csz);     // dWx (unfused path) or the 16-bit row indices (fused path)
+  if (!pl->all_tiled) off += align((long long)pl->na * pl->N * csz);   // dWx (unfused path) or row indices (fused path)
   L.xc = off;                  // register-core path: the transposed, residue-twiddled spectrum
   if (pl->reg) off += align(((long long)pl->reg_D << 20) * csz);
   L.os_xs = off;               // time-tiled path: the tiles' spectra
@@ -564,7 +565,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   q.gamma = (T)(gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma);       // ssq_cwt.rs:438-441
   q.leb_val = (T)(1.0 / (double)n);
   const long long plane = (long long)n * pl->N;
-  if (pl->fused_ssq()) {
+  if (pl->fused_ssq() && !pl->all_tiled) {
     if (!pl->side) {
       SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
       SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
@@ -593,7 +594,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     }
     return 0;
   }
-  const int group = pl->can_fuse_ssq() ? ssq_group_env(0) : 0;
+  const int group = (pl->can_fuse_ssq() && !pl->all_tiled) ? ssq_group_env(0) : 0;
   // reassignment with a written-rows bitmap (first run of a row: plain store).  SSQ_CWT_SWEEP: 0 = read-modify-write
   // of a cleared Tx; 1 (default) = bitmap, Tx cleared beside the transforms; 2 = bitmap and the kernel writes the
   // untouched rows as zeros itself, no clear (measured slower on C4: the clear overlaps the transforms, the zero rows
@@ -639,13 +640,15 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     } else if (os) {
       if constexpr (sizeof(T) == 4) {
         // every other scale through the transforms into the workspaces ...
-        if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_mask.data())) return rc;
-        if (d_dbg_Wx)
-          SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
-                                 hipMemcpyDeviceToDevice, st));
-        if (d_dbg_dWx)
-          SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_dWx + b * plane, dW, (size_t)plane * sizeof(cpx<T>),
-                                 hipMemcpyDeviceToDevice, st));
+        if (!pl->all_tiled) {
+          if (int rc = run_inverse<T>(pl, p, W, dW, true, false, st, NoAfter(), 0, pl->os_mask.data())) return rc;
+          if (d_dbg_Wx)
+            SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_Wx + b * plane, W, (size_t)plane * sizeof(cpx<T>),
+                                   hipMemcpyDeviceToDevice, st));
+          if (d_dbg_dWx)
+            SSQ_HIP(hipMemcpyAsync((cpx<T>*)d_dbg_dWx + b * plane, dW, (size_t)plane * sizeof(cpx<T>),
+                                   hipMemcpyDeviceToDevice, st));
+        }
         SSQ_HIP(hipStreamWaitEvent(st, pl->ev_join, 0));           // Tx is clear from here on
         // the scales in FRONT of the tiled ones first, while Tx is still empty: with the written-rows bitmap their runs
         // are plain stores (behind the tile kernels each would be a dependent read-modify-write chain per column)
@@ -915,6 +918,8 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
     pl->os_mask.assign((size_t)(na > 0 ? na : 1), 0);
     for (int i = (pl->os_s1 > pl->os_s0 ? pl->os_a0 : 0); i < pl->os_d1; ++i) pl->os_mask[(size_t)i] = 1;
     for (int i = pl->os_z0; i < pl->os_z1; ++i) pl->os_mask[(size_t)i] = 1;
+    pl->all_tiled = na > 0;
+    for (int64_t i = 0; i < na; ++i) pl->all_tiled = pl->all_tiled && pl->os_mask[(size_t)i];
   }
   int rc = dtype == SSQ_F32 ? build_tables<float>(pl) : build_tables<double>(pl);
   if (rc) {
