@@ -323,6 +323,49 @@ def roofline_of(leg, kern_ms, traffic, kernel_name):
             "alg_bytes_per_launch": alg}
 
 
+def cwt_c4_leg(lib, _lib, steps=5):
+    """BASELINE config 4 through the plan API (tools/bench_cwt.py is the full tool): ms per call, bins/s and the
+    algorithmic-bytes fraction of the HBM roof; traffic from the committed PMC passes if present."""
+    import ctypes as C
+    from ssqueeze_rs_amd.synth import synth_signal
+    N, na = 1 << 20, 256
+    scales = 2.0 ** np.linspace(1, 19, na)
+    plan, dx, dT, ws = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(lib.ssq_cwt_plan_create(C.byref(plan), _lib.SSQ_F32, N, _lib.WAVELET["morlet"],
+                                       scales.ctypes.data_as(C.c_void_p), na, 1.0, 0))
+    wsb = lib.ssq_cwt_plan_workspace_bytes(plan, 1)
+    try:
+        _lib.check(lib.ssq_dev_malloc(C.byref(dx), N * 4))
+        _lib.check(lib.ssq_dev_malloc(C.byref(dT), na * N * 8))
+        _lib.check(lib.ssq_dev_malloc(C.byref(ws), wsb))
+        x = synth_signal(N, 0, np.float32)
+        _lib.check(lib.ssq_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes, None))
+
+        def run():
+            _lib.check(lib.ssq_cwt_plan_exec_ssq(plan, dx, 1, 0, 0, 0, 1, -1.0, dT, None, None, None, ws, wsb, None))
+            _lib.check(lib.ssq_device_sync())
+
+        run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        for ptr in (dx, dT, ws):
+            if ptr:
+                lib.ssq_dev_free(ptr)
+        lib.ssq_cwt_plan_destroy(plan)
+    alg = 4 * N + 8 * na * N
+    out = {"workload": "ssq_cwt morlet, 256 log scales, 1 x 2^20, fp32", "ms_per_call": dt * 1e3,
+           "value": na * N / dt, "unit": "TF-bins/s", "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+           "workspace_GB": wsb / 1e9}
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_cwt_traffic.json")
+    if os.path.exists(tf):
+        with open(tf) as fh:
+            out["traffic_over_algorithmic"] = json.load(fh)["total_GB_per_call"] * 1e9 / alg
+    return out
+
+
 def main():
     args = parse_args()
     plan = launch_plan(args.gpus)
@@ -411,6 +454,11 @@ def main():
                       "value": B * l64.bins / (float(np.mean(k64)) * 1e-3), "unit": "TF-bins/s",
                       "roofline": r64, "validated": None if v64 is None else v64["ok"]}
         l64.close()
+        # (3) BASELINE config 4: ssq_cwt, 1 x 2^20, 256 log scales, Morlet, fp32 (wall clock around synchronised calls)
+        try:
+            sec["c4_ssq_cwt_f32"] = cwt_c4_leg(lib, _lib)
+        except Exception as e:                                    # a secondary leg must not take the headline down
+            sec["c4_ssq_cwt_f32"] = {"error": str(e)}
 
     wall, kern_ms = leg.timed(args.steps, args.warmup, before=fence, after=torch.cuda.synchronize,
                               settle_ms=args.settle_ms)
