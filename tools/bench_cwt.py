@@ -21,6 +21,7 @@ ap.add_argument("--na", type=int, default=256)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--wavelet", default="morlet")
 a = ap.parse_args()
 lib = _lib.load()
 N, na, B = 1 << a.log2n, a.na, a.batch
@@ -28,7 +29,7 @@ code = _lib.SSQ_F32 if a.dtype == "f32" else _lib.SSQ_F64
 es = 4 if code == _lib.SSQ_F32 else 8
 scales = 2.0 ** np.linspace(1, a.log2n - 1, na)
 plan = C.c_void_p()
-_lib.check(lib.ssq_cwt_plan_create(C.byref(plan), code, N, _lib.WAVELET["morlet"], scales.ctypes.data_as(C.c_void_p),
+_lib.check(lib.ssq_cwt_plan_create(C.byref(plan), code, N, _lib.WAVELET[a.wavelet], scales.ctypes.data_as(C.c_void_p),
                                    na, 1.0, 0))
 wsb = lib.ssq_cwt_plan_workspace_bytes(plan, B)
 dx, dT, ws = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -61,10 +62,10 @@ flops = B * ((1 + 2 * na) * 5.0 * P * lp + 2 * na * 4.0 * P + 30.0 * na * N)
 vec_peak = 157.3e12 if es == 4 else 78.6e12
 traffic = None
 tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_cwt_traffic.json")
-if a.log2n == 20 and na == 256 and es == 4 and os.path.exists(tf):
+if a.log2n == 20 and na == 256 and es == 4 and a.wavelet == "morlet" and os.path.exists(tf):
     with open(tf) as fh:
         traffic = json.load(fh)["total_GB_per_call"] * 1e9 * B
-print(json.dumps({"workload": f"ssq_cwt morlet na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
+print(json.dumps({"workload": f"ssq_cwt {a.wavelet} na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
                   "bins_per_s": bins / dt, "alg_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                   "roofline_hbm": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": alg / dt / 8e12, "traffic": traffic,
