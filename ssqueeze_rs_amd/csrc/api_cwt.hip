@@ -721,6 +721,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
           o.H = (const float*)pl->d_osHz;
           o.xh = p.xh;
           o.log_dec = pl->logP - 12;
+          o.full_n0 = pl->P / 4 - pl->n1;                        // <= 0: the emitted window covers [n1, n1 + N)
           o.s_begin = pl->os_z0;
           o.s_end = pl->os_z1;
           o.xi_step = (float)((2.0 * M_PI / (double)pl->P) / pl->dt);
@@ -897,13 +898,13 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
       }
     }
   }
-  // full-circle phase blocks for the band-limited scales: P = 2 N (the kept samples are the middle half of the padded
-  // length), spectrum below 2048 bins; SSQ_CWT_OS_FULL=0 keeps mode Z + the column reassignment for them
+  // full-circle phase blocks for the band-limited scales: 2 N <= P (the kept samples lie inside the middle half of the
+  // padded length, which is what the tile kernel emits), spectrum below 2048 bins; SSQ_CWT_OS_FULL=0 keeps mode Z + the column reassignment for them
   {
     const char* e = std::getenv("SSQ_CWT_OS");
     const char* ef = std::getenv("SSQ_CWT_OS_FULL");
     if (dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0) && !(ef && std::atoi(ef) == 0) &&
-        pl->P == 2 * pl->N && n_signal >= 64LL * kOsL) {
+        2 * pl->N <= pl->P && n_signal >= 64LL * kOsL) {
       bool ascending = true;
       for (int64_t i = 1; i < na; ++i) ascending = ascending && scales[i] >= scales[i - 1];
       int z0 = pl->os_d1;

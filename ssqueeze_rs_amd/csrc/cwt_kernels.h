@@ -146,6 +146,7 @@ struct CwtOsDev {
   cpx<float>* xs;              // scratch [tiles][F / 2]: the tiles' spectra (k < F / 2)
   const cpx<float>* xh;        // full-circle mode: the padded signal's spectrum in natural order
   int log_dec;                 // full-circle mode: log2(P / 4096)
+  long long full_n0;           // full-circle mode: P / 4 - n1 (unpadded time of the emitted window's first sample)
   const cpx<float>* xa;        // analytic-input tiles: ifft_P(X 1[k <= P/2]) on the padded grid
   long long xa_off;            //   index of unpadded time 0 in xa (= n1)
   const float* H;              // [s_end - s_begin][F / 2] psih(scale * 2 pi k / F)
@@ -164,7 +165,7 @@ hipError_t launch_cwt_os_table(float* H, const double* d_scales, int s_begin, in
 // the finest scales (psih not negligible at Nyquist) on 4096-point tiles of the analytic signal p.xa
 hipError_t launch_cwt_os_analytic(const CwtOsDev& p, hipStream_t stream);
 hipError_t launch_cwt_os(const CwtOsDev& p, int rows, int log_dec, hipStream_t stream);
-// band-limited scales (spectrum below 2048 bins) of plans with P = 2 N: one output phase per block over the whole padded
+// band-limited scales (spectrum below 2048 bins) of plans with 2 N <= P: one output phase per block over the whole padded
 // signal (4096-point transforms on the P / 4096-fold decimated grid), bins and run merge on chip
 hipError_t launch_cwt_os_full(const CwtOsDev& p, hipStream_t stream);
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
 // where X_seg[k], k < F/2, are the low bins of the S-point spectrum of the segment (cwt_os_dec_fwd_kernel: one F-point
 // transform per input phase, summed here).  The M phases of a tile run on the same XCD, so their 8-byte read-modify-
 // writes of neighbouring Tx columns meet in one L2.
-// LOGM < 0 (FULL circle, decimation 2^p.log_dec chosen at run time with S = F M = the padded length P, for P = 2 N):
+// LOGM < 0 (FULL circle, decimation 2^p.log_dec chosen at run time with S = F M = the padded length P, for 2 N <= P):
 // the "segment" is the whole padded signal, so the circular convolution is the reference's own, exact for every scale
 // whose spectrum ends below F / 2 bins -- the band-limited scales of mode Z -- and X_seg is simply the spectrum xh the
 // forward transform of the call has left in natural order; ONE tile, P / F phases = blocks.
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
       phase = bid & (M - 1);
     }
   }
-  const long long n0 = (long long)tile * ((long long)L << logm);   // first output sample of the tile (unpadded time)
+  // first output sample of the tile in unpadded time; FULL: the window [P/4, 3P/4) of the padded signal starts at
+  // unpadded time P/4 - n1 <= 0 (2 N <= P), columns outside [0, N) are dropped
+  const long long n0 = FULL ? p.full_n0 : (long long)tile * ((long long)L << logm);
   cpx<float>* __restrict__ xs = p.xs + (long long)tile * NS * M;        // (unused when FULL)
   __syncthreads();
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
       const cpx<float> dW = zb[1][(nl & (R - 1)) * PT + (nl >> LOGR)];
       fl_ptr[i] = nullptr;
       fl_val[i] = {0.0f, 0.0f};
-      if (col < q.N) {
+      if (col >= 0 && col < q.N) {
         if (p.dbg_Wx) p.dbg_Wx[(long long)s * q.N + col] = Wv;
         if (p.dbg_dWx) p.dbg_dWx[(long long)s * q.N + col] = dW;
         float w;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long long col = n0 + ((long long)(tid + THREADS * i) << logm) + phase;
-    if (col < q.N && k_cur[i] >= 0) flush(i, col);
+    if (col >= 0 && col < q.N && k_cur[i] >= 0) flush(i, col);
   }
 }
 

@@ -368,7 +368,7 @@ def test_ssq_cwt_register_core_one_residue(monkeypatch):
         assert np.abs(cs - cs0).max() <= 1e-3 * np.abs(cs0).max()
 
 
-@pytest.mark.parametrize("N", [(1 << 20) - 1234, 1 << 19])
+@pytest.mark.parametrize("N", [(1 << 20) - 1234, 1 << 19, 700_000])
 @pytest.mark.parametrize("wavelet", ["morlet", "gmw"])
 def test_ssq_cwt_time_tiled_scales(wavelet, N, monkeypatch):
     """fp32 plans at C4's geometry run the scales whose wavelet is short in time by overlap-save tiles
@@ -378,7 +378,8 @@ def test_ssq_cwt_time_tiled_scales(wavelet, N, monkeypatch):
     all but a handful of elements, the same Tx column sums -- and the oracle's Wx on a subset of the tiled scales.
     N = 2^20 - 1234 is not a multiple of the tile length (a partial last tile); N = 2^19 has P = 2 N, where the
     band-limited scales too run as phase blocks over the whole padded signal (exact circular convolution, the
-    reference's own) instead of mode Z + the column reassignment."""
+    reference's own) instead of mode Z + the column reassignment; N = 700 000 has 2 N < P = 2^21 (the same blocks, their
+    window wider than the kept samples)."""
     x = _sig(N, 41, np.float32)
     scales = 2.0 ** np.linspace(1.0, 19.0, 64)
     Tx, f, dbg = _rs.ssq_cwt(x, wavelet=wavelet, scales=scales, _debug=True)
