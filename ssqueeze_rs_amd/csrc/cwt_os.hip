@@ -22,6 +22,10 @@
 
 namespace ssq {
 
+#ifndef SSQ_OS_WAVES_PER_SIMD
+#define SSQ_OS_WAVES_PER_SIMD 4     // 4: 128 VGPRs (two 8-wave blocks per CU); 2: 256 VGPRs, no spills, one 8-wave block per CU
+#endif
+
 namespace {
 
 template <int R>
@@ -79,7 +83,7 @@ __device__ __forceinline__ void os_dft(cpx<float> (&v)[R]) {
 // the input that cut is already in the signal, the filter stays smooth -- hence short in time -- and the finest scales,
 // whose psih is NOT negligible at Nyquist, become tile-able as well.
 template <int R, int LOGM, bool CPLX = false>
-__global__ __launch_bounds__(OsCfg<R>::THREADS, 4) void cwt_os_kernel(CwtOsDev p) {
+__global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_os_kernel(CwtOsDev p) {
   using K = OsCfg<R>;
   constexpr int F = K::F, L = K::L, HALO = K::HALO, THREADS = K::THREADS, PT = K::PT, LOGR = K::LOGR;
   constexpr int H2 = CPLX ? R : R / 2;                         // live rows of the spectrum
