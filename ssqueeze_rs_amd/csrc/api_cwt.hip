@@ -519,16 +519,91 @@ int run_inverse_ssq(const ssq_cwt_plan* pl, CwtDev<T> p, const CwtSsqDev<T>& q, 
   return 0;
 }
 
+// the analytic signal xa = ifft_P(X 1[k <= P/2]) of the padded signal into the workspace: the register-core transform of
+// the pseudo-scale "one" (register-core plans; p.xh must hold the forward transform)
+template <typename T>
+int analytic_signal(const ssq_cwt_plan* pl, const CwtDev<T>& p, char* ws, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    const WsLayout L = ws_layout(pl);
+    CwtDev<T> pa = p;
+    pa.scale0 = 0;
+    pa.n_kinds = 1;
+    pa.n_transforms = 1;
+    pa.rpadded = 1;
+    pa.cols = pl->P;
+    CwtRegDev r = reg_dev<T>(pl, pa);
+    r.psiT = (const float*)pl->d_xa_psiT;
+    r.psiT_off = pl->d_xa_off;
+    r.psiT_A = pl->d_xa_int;
+    r.band = pl->d_xa_int + 1;
+    r.psih = (const float*)pl->d_xa_psiT;
+    r.psi_off = pl->d_xa_off + 1;
+    r.out_scale = pl->d_xa_scale;
+    r.Wx = (cpx<float>*)(ws + L.xa);
+    r.dWx = nullptr;
+    SSQ_HIP(launch_cwt_reg_inv(r, pl->n_cus, st));
+  }
+  return 0;
+}
+
 template <typename T>
 int exec_cwt_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, bool l1, bool rpadded, void* d_Wx,
                    void* d_dWx, char* ws, hipStream_t st) {
   const long long cols = rpadded ? pl->P : pl->N;
+  // The short-wavelet scales by time tiles that store Wx / dWx (contiguous columns: the analytic-input and the plain
+  // groups; the decimated and full-circle groups would write 8-byte pieces); SSQ_CWT_OS_STORE=0 keeps the transforms
+  const char* es = std::getenv("SSQ_CWT_OS_STORE");
+  const bool tiles = sizeof(T) == 4 && !rpadded && d_dWx && pl->os_s1 > pl->os_s0 && !(es && std::atoi(es) == 0);
+  std::vector<char> mask;
+  if (tiles) {
+    mask.assign((size_t)pl->na, 0);
+    for (int i = pl->os_a0; i < pl->os_s1; ++i) mask[(size_t)i] = 1;
+  }
+  const WsLayout L = ws_layout(pl);
   for (long long b = 0; b < batch; ++b) {
     CwtDev<T> p = base_dev<T>(pl, ws);
     if (int rc = run_forward<T>(pl, p, (const T*)d_x + b * pl->N, st)) return rc;
     cpx<T>* W = (cpx<T>*)d_Wx + b * pl->na * cols;
     cpx<T>* dW = d_dWx ? (cpx<T>*)d_dWx + b * pl->na * cols : nullptr;
-    if (int rc = run_inverse<T>(pl, p, W, dW, l1, rpadded, st)) return rc;
+    if (int rc = run_inverse<T>(pl, p, W, dW, l1, rpadded, st, NoAfter(), 0, tiles ? mask.data() : nullptr)) return rc;
+    if constexpr (sizeof(T) == 4) {
+      if (tiles) {
+        CwtOsDev o;
+        std::memset(&o, 0, sizeof(o));
+        o.x = (const float*)d_x + b * pl->N;
+        o.xs = (cpx<float>*)(ws + L.os_xs);
+        o.tw1024 = (const cpx<float>*)pl->d_tw1024;
+        o.q.N = pl->N;
+        o.q.na = pl->na;
+        o.dbg_Wx = (cpx<float>*)W;
+        o.dbg_dWx = (cpx<float>*)dW;
+        o.store_only = 1;
+        o.out_mul = l1 ? nullptr : (const float*)pl->d_scale_l2;     // sqrt(a) / P: inv_F below carries the P
+        o.n_signal = pl->N;
+        o.padtype = pl->padtype;
+        const double mulP = l1 ? 1.0 : (double)pl->P;
+        if (pl->os_s0 > pl->os_a0) {
+          if (int rc = analytic_signal<T>(pl, p, ws, st)) return rc;
+          o.xa = (const cpx<float>*)(ws + L.xa);
+          o.xa_off = pl->n1;
+          o.H = (const float*)pl->d_osHa;
+          o.s_begin = pl->os_a0;
+          o.s_end = pl->os_s0;
+          o.xi_step = (float)((2.0 * M_PI / 4096.0) / pl->dt);
+          o.inv_F = (float)(mulP / 4096.0);
+          SSQ_HIP(launch_cwt_os_analytic(o, st));
+        }
+        for (int rows = 4; rows <= 8; rows += 4) {
+          const double F = 1024.0 * rows;
+          o.H = (const float*)(rows == 4 ? pl->d_osH4 : pl->d_osH);
+          o.s_begin = rows == 4 ? pl->os_s0 : pl->os_mid;
+          o.s_end = rows == 4 ? pl->os_mid : pl->os_s1;
+          o.xi_step = (float)((2.0 * M_PI / F) / pl->dt);
+          o.inv_F = (float)(mulP / F);
+          SSQ_HIP(launch_cwt_os(o, rows, 0, st));
+        }
+      }
+    }
   }
   return 0;
 }
@@ -672,24 +747,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
         o.n_signal = pl->N;
         o.padtype = pl->padtype;
         if (pl->os_s0 > pl->os_a0) {
-          // the analytic signal xa = ifft_P(X 1[k <= P/2]): the register-core transform of the pseudo-scale "one"
-          CwtDev<T> pa = p;
-          pa.scale0 = 0;
-          pa.n_kinds = 1;
-          pa.n_transforms = 1;
-          pa.rpadded = 1;
-          pa.cols = pl->P;
-          CwtRegDev r = reg_dev<T>(pl, pa);
-          r.psiT = (const float*)pl->d_xa_psiT;
-          r.psiT_off = pl->d_xa_off;
-          r.psiT_A = pl->d_xa_int;
-          r.band = pl->d_xa_int + 1;
-          r.psih = (const float*)pl->d_xa_psiT;
-          r.psi_off = pl->d_xa_off + 1;
-          r.out_scale = pl->d_xa_scale;
-          r.Wx = (cpx<float>*)(ws + L.xa);
-          r.dWx = nullptr;
-          SSQ_HIP(launch_cwt_reg_inv(r, pl->n_cus, st));
+          if (int rc = analytic_signal<T>(pl, p, ws, st)) return rc;
           o.xa = (const cpx<float>*)(ws + L.xa);
           o.xa_off = pl->n1;
           o.H = (const float*)pl->d_osHa;

@@ -152,8 +152,10 @@ struct CwtOsDev {
   const float* H;              // [s_end - s_begin][F / 2] psih(scale * 2 pi k / F)
   const cpx<float>* tw1024;    // W_1024^j
   CwtSsqDev<float> q;          // binning parameters, Tx (zero or partial sums on entry), optional (w, k) hook
-  cpx<float>* dbg_Wx;          // optional [na][N] debug copies
+  cpx<float>* dbg_Wx;          // optional [na][N] copies of Wx / dWx (the `_debug` hooks; the RESULT when store_only)
   cpx<float>* dbg_dWx;
+  int store_only;              // `cwt`: write Wx / dWx and skip the bins / Tx
+  const float* out_mul;        // optional per-scale factor on top of inv_F (cwt with the L2 norm)
   long long n_signal;
   int padtype;
   int s_begin, s_end;          // scales of this launch (ascending)

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
           for (int r = 0; r < H2; ++r) hk[u][r] = Hn[1024 * r + tid + THREADS * u];
       }
       wave1024_back(v, tw1, tw2, t);
-      const float sc = p.inv_F;
+      const float sc = p.out_mul ? p.inv_F * p.out_mul[s] : p.inv_F;   // (cwt with the L2 norm: times sqrt(scale))
 #pragma unroll
       for (int i = 0; i < 16; ++i) myrow[t + 64 * i] = {v[i].x * sc, -v[i].y * sc};
     }
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
       if (col >= 0 && col < q.N) {
         if (p.dbg_Wx) p.dbg_Wx[(long long)s * q.N + col] = Wv;
         if (p.dbg_dWx) p.dbg_dWx[(long long)s * q.N + col] = dW;
+        if (p.store_only) continue;                              // `cwt`: Wx / dWx are the result, no bins
         float w;
         const int kk = reassign_bin(q, Wv, dW, w);
         if (q.wk) q.wk[(long long)s * q.N + col] = {w, (float)kk};

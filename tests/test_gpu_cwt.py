@@ -304,6 +304,7 @@ def test_cwt_register_core_path(wavelet, N, monkeypatch):
     k = P/2 term) run their two-step scales on the per-wave register FFT core (csrc/cwt_reg.hip).  Per scale against the
     oracle, and against the tile kernels (SSQ_CWT_REG=0) to rounding; the scales sit on both sides of the band switch
     (full band with a live k = P/2 term, partly dead rows, single-pass scales)."""
+    monkeypatch.setenv("SSQ_CWT_OS_STORE", "0")          # (the tiles that store Wx / dWx have their own test)
     x = _sig(N, 5, np.float32)
     scales = np.array([1.0, 1.7, 3.1, 6.0, 19.0, 77.0, 150.0, 900.0, 20000.0])
     Wx, sc, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, fs=20.0, l1_norm=False, derivative=True)
@@ -442,3 +443,27 @@ def test_ssq_cwt_time_tiled_options(opts, monkeypatch):
     assert (np.abs(cs - cs0) > 1e-3 * np.abs(cs0).max()).mean() <= 2e-3
     re, re0 = (np.abs(Tx.astype(np.complex128)) ** 2).sum(1), (np.abs(Tx0.astype(np.complex128)) ** 2).sum(1)
     assert np.abs(re - re0).max() <= 2e-3 * re0.max()
+
+
+@pytest.mark.parametrize("l1_norm", [True, False])
+def test_cwt_short_wavelet_scales_by_storing_tiles(l1_norm, monkeypatch):
+    """`cwt` with the derivative runs the scales whose wavelet is short in time (and, on register-core plans, the finest
+    ones through the analytic signal) on the same time tiles as ssq_cwt, which then STORE Wx / dWx instead of binning
+    them; SSQ_CWT_OS_STORE=0 keeps the frequency-domain transforms.  Per scale to fp32 rounding against those and against
+    the oracle, both norms, N not a multiple of the tile length."""
+    N = (1 << 20) - 777
+    x = _sig(N, 71, np.float32)
+    scales = 2.0 ** np.linspace(1.0, 12.0, 23)
+    Wx, sc, dWx = _rs.cwt(x, wavelet="morlet", scales=scales, fs=4.0, l1_norm=l1_norm, derivative=True)
+    monkeypatch.setenv("SSQ_CWT_OS_STORE", "0")
+    Wx0, _, dWx0 = _rs.cwt(x, wavelet="morlet", scales=scales, fs=4.0, l1_norm=l1_norm, derivative=True)
+    differ = [i for i in range(len(scales)) if not np.array_equal(Wx[i], Wx0[i])]
+    assert len(differ) >= 10
+    for a, b in ((Wx, Wx0), (dWx, dWx0)):
+        row_max = np.abs(b).max(axis=1, keepdims=True)
+        assert (np.abs(a - b) <= 1e-5 * row_max).all()
+    sub = np.array(differ[::4])
+    Wx_o, _, dWx_o = o.cwt(x.astype(np.float64), "morlet", scales=scales[sub], fs=4.0, l1_norm=l1_norm, derivative=True)
+    for j, i in enumerate(sub):
+        assert np.abs(Wx[i] - Wx_o[j]).max() <= 2e-5 * np.abs(Wx_o[j]).max(), i
+        assert np.abs(dWx[i] - dWx_o[j]).max() <= 2e-5 * np.abs(dWx_o[j]).max(), i
