@@ -457,6 +457,11 @@ def test_cwt_short_wavelet_scales_by_storing_tiles(l1_norm, monkeypatch):
     Wx, sc, dWx = _rs.cwt(x, wavelet="morlet", scales=scales, fs=4.0, l1_norm=l1_norm, derivative=True)
     monkeypatch.setenv("SSQ_CWT_OS_STORE", "0")
     Wx0, _, dWx0 = _rs.cwt(x, wavelet="morlet", scales=scales, fs=4.0, l1_norm=l1_norm, derivative=True)
+    if l1_norm:                                           # a batch of two through one workspace = the single calls
+        xb = np.stack([x, _sig(N, 72, np.float32)])
+        Wb, _, dWb = _rs.cwt(xb, wavelet="morlet", scales=scales[:6], fs=4.0, l1_norm=True, derivative=True)
+        W1, _, dW1 = _rs.cwt(xb[1], wavelet="morlet", scales=scales[:6], fs=4.0, l1_norm=True, derivative=True)
+        assert np.array_equal(Wb[1], W1) and np.array_equal(dWb[1], dW1)
     differ = [i for i in range(len(scales)) if not np.array_equal(Wx[i], Wx0[i])]
     assert len(differ) >= 10
     for a, b in ((Wx, Wx0), (dWx, dWx0)):
