@@ -22,7 +22,7 @@ ap.add_argument("--dtype", default="f32")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--wavelet", default="morlet")
-ap.add_argument("--mode", default="ssq", help="ssq (ssq_cwt) | cwt (Wx and dWx out, L1 norm, unpadded)")
+ap.add_argument("--mode", default="ssq", help="ssq (ssq_cwt) | cwt (Wx and dWx out, L1 norm, unpadded) | cwt1 (Wx only)")
 a = ap.parse_args()
 lib = _lib.load()
 N, na, B = 1 << a.log2n, a.na, a.batch
@@ -48,8 +48,8 @@ if a.mode == "cwt":
 
 
 def run():
-    if a.mode == "cwt":
-        _lib.check(lib.ssq_cwt_plan_exec_cwt(plan, dx, B, 1, 0, dT, dW, ws, wsb, None))
+    if a.mode in ("cwt", "cwt1"):
+        _lib.check(lib.ssq_cwt_plan_exec_cwt(plan, dx, B, 1, 0, dT, dW if a.mode == "cwt" else None, ws, wsb, None))
     else:
         _lib.check(lib.ssq_cwt_plan_exec_ssq(plan, dx, B, 0, 0, 0, 1, -1.0, dT, None, None, None, ws, wsb, None))
     _lib.check(lib.ssq_device_sync())
@@ -74,7 +74,7 @@ tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
 if a.log2n == 20 and na == 256 and es == 4 and a.wavelet == "morlet" and os.path.exists(tf):
     with open(tf) as fh:
         traffic = json.load(fh)["total_GB_per_call"] * 1e9 * B
-print(json.dumps({"workload": f"{a.mode if a.mode == 'cwt' else 'ssq_cwt'} {a.wavelet} na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
+print(json.dumps({"workload": f"{a.mode if a.mode != 'ssq' else 'ssq_cwt'} {a.wavelet} na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
                   "bins_per_s": bins / dt, "alg_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                   "roofline_hbm": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": alg / dt / 8e12, "traffic": traffic,
