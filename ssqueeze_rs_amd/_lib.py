@@ -153,16 +153,26 @@ class _PinnedBlock:
         self.ptr = None
 
 
+# Results above this size come from pageable memory: page-locking tens of GB (C5: 17.2 GB of Tx per fp64 signal) can
+# fail or stall the host.  Override with the environment (bytes); 0 switches the pinned pool off for results.
+PINNED_RESULT_LIMIT = int(os.environ.get("SSQ_PINNED_RESULT_LIMIT", str(4 << 30)))
+
+
 def pinned_empty(shape, dtype):
     """`np.empty(shape, dtype)` in pinned host memory from the library's pool: device results land in it by DMA, no
     page faults, no staging copy.  An ordinary writable ndarray for the caller; the block goes back to the pool when
-    the array (and every view of it) is garbage-collected.  Falls back to np.empty when no GPU is visible."""
+    the array (and every view of it) is garbage-collected.  Falls back to np.empty (pageable) when no GPU is visible,
+    when the array is larger than PINNED_RESULT_LIMIT, or when the pinned allocation fails -- the drop-in call must
+    not fail where the reference's `np.empty` would succeed."""
     import numpy as np
     dt = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-    if n == 0 or device_count() < 1:
+    if n == 0 or n > PINNED_RESULT_LIMIT or device_count() < 1:
         return np.empty(shape, dtype=dt)
-    blk = _PinnedBlock(n)
+    try:
+        blk = _PinnedBlock(n)
+    except SsqHipError:
+        return np.empty(shape, dtype=dt)
     raw = (C.c_char * n).from_address(blk.ptr.value)
     raw._ssq_owner = blk                    # the ctypes array is the ndarray's base: it keeps the block alive
     return np.frombuffer(raw, dtype=dt).reshape(shape)

@@ -909,10 +909,19 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = ssq_stamp();
 #endif
+  // (ablation bit 0x100, timing only / racy: ONE barrier per tile and an ASYMMETRIC wave schedule -- the waves with
+  // (fl & ((ablate >> 12) & 15)) != 0 read the previous tile out BEFORE their frame, the others AFTER their scatter, so
+  // that every SIMD has LDS/store-bound and VALU-bound waves at the same time; prices a double-buffered tile)
+  const bool asym = SSQ_ABL(0x100);
+  const bool asym_early = asym && ((fl & ((p.ablate >> 12) & 15)) != 0);
+  bool have_prev = false;
+  long long psig = 0;
+  int pframe0 = 0;
 #pragma unroll 1
   while (true) {
     const int frame0 = tile_frame0(jt);
     const bool valid = EDGE ? (frame0 + fl < p.n_frames) : true;
+    if (asym_early && have_prev) read_out(psig, pframe0);
     cpx<T> v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1167,6 +1176,13 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // charge the atomics' drain to their own phase
 #endif
     SSQ_STAMP(6);
+    if (asym) {
+      if (!asym_early && have_prev) read_out(psig, pframe0);
+      __syncthreads();
+      have_prev = true;
+      psig = sig;
+      pframe0 = frame0;
+    } else {
     __syncthreads();
     SSQ_STAMP(7);
 #if SSQ_PRIO & 2
@@ -1178,11 +1194,13 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 #endif
     SSQ_STAMP(8);
     if (!SSQ_ABL(64)) __syncthreads();      // (ablation bit 64: what ONE barrier per tile would buy -- racy, results wrong)
+    }
     SSQ_STAMP(9);
     if (!has_next) break;
     sig = nsig;
     jt = njt;
   }
+  if (asym && have_prev) read_out(psig, pframe0);
 #ifdef SSQ_STAMPS
   if (p.stamps && t == 0)
     for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * H::W + fl) * 12 + i] = st_acc[i];

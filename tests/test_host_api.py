@@ -80,3 +80,40 @@ def test_argument_errors_raised_before_any_gpu_work():
     with pytest.raises(_rs.PanicException):
         _rs.ssq_cwt(x, scales=np.zeros(0))                       # scales[len-1] (:459)
     assert not issubclass(_rs.PanicException, Exception)         # like pyo3_runtime.PanicException
+
+
+def test_reference_import_line_runs_unchanged():
+    """/root/reference README.md:74-79 and src/ssqueeze/__init__.py:2-3: `from ssqueeze import _rs`."""
+    import importlib
+    ssq = importlib.import_module("ssqueeze")
+    assert ssq._rs is _rs and ssq.__all__ == ["_rs"]
+    from ssqueeze import _rs as rs2
+    from ssqueeze._rs import ssq_stft
+    assert rs2 is _rs and ssq_stft is _rs.ssq_stft
+    assert rs2.hello_from_bin() == "Hello from ssqueeze!"
+
+
+def test_pinned_empty_falls_back_to_pageable_memory(monkeypatch):
+    """a failing page-locked allocation (or an array above the limit) must still give a usable ndarray."""
+    from ssqueeze_rs_amd import _lib
+
+    class Boom:
+        def __init__(self, nbytes):
+            raise _lib.SsqHipError("hipHostMalloc failed (test)")
+
+    monkeypatch.setattr(_lib, "device_count", lambda: 1)
+    monkeypatch.setattr(_lib, "_PinnedBlock", Boom)
+    a = _lib.pinned_empty((3, 5), np.complex64)
+    assert a.shape == (3, 5) and a.dtype == np.complex64 and a.flags.writeable
+    a[:] = 1
+    calls = []
+
+    class Count:
+        def __init__(self, nbytes):
+            calls.append(nbytes)
+            raise _lib.SsqHipError("x")
+
+    monkeypatch.setattr(_lib, "_PinnedBlock", Count)
+    monkeypatch.setattr(_lib, "PINNED_RESULT_LIMIT", 16)
+    b = _lib.pinned_empty((4, 4), np.float64)            # 128 B > limit: the pool is not even asked
+    assert b.shape == (4, 4) and calls == []
