@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "fft_core.h"
+#include "fft_pk1024.h"
 #include "stft_kernels.h"
 
 namespace ssq {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
     load_samples<T, LOGN, EDGE, BLUE>(p, i1.tl, fr1, xb, t);
   }
 #ifdef SSQ_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = ssq_stamp();
 #endif
 
@@ -721,6 +722,11 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #ifndef SSQ_RO_PAIR
 #define SSQ_RO_PAIR 1              // 1: read-out of the interior 16-wave kernel with 16-byte stores (two frames per thread)
 #endif
+#ifndef SSQ_PK
+#define SSQ_PK 0                   // 1: the 16-wave kernel's FFT on packed fp32 (fft_pk1024.h): 25 % fewer vector instructions,
+                                   // SAME time (-1.5 %; VALU-only floor 1.52 vs 1.46 ms): two waves already share the SIMD's 32
+                                   // lanes for scalar fp32 add/mul/fma, a packed op takes the slot of two (profiles/r03_ab_pk.txt)
+#endif
 #ifndef SSQ_TX_MERGE
 #define SSQ_TX_MERGE 0      // (measured: a net loss since the read-out/exchange rework, profiles/r02_ab_libs2.txt) merge the contributions of lane pairs with equal destinations before the LDS atomic
 #endif
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   };
 
 #ifdef SSQ_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = ssq_stamp();
 #endif
   // (ablation bit 0x100, timing only / racy: ONE barrier per tile and an ASYMMETRIC wave schedule -- the waves with
@@ -922,13 +928,6 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     const int frame0 = tile_frame0(jt);
     const bool valid = EDGE ? (frame0 + fl < p.n_frames) : true;
     if (asym_early && have_prev) read_out(psig, pframe0);
-    cpx<T> v[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const cpx<T> wq = win_lds[t + L * q];
-      v[q] = {xn[q] * wq.x, xn[q] * wq.y};
-    }
-    SSQ_STAMP(0);
     // next tile of this block; prefetch its samples behind this frame's FFT
     long long nsig = sig;
     int njt = jt + (int)gridDim.x;
@@ -937,6 +936,77 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
       ++nsig;
     }
     const bool has_next = nsig < n_sig;
+    cpx<T> v[16];
+#if SSQ_PK
+    constexpr bool kPk = (WAVES == 16);
+#else
+    constexpr bool kPk = false;
+#endif
+    if constexpr (kPk) {
+      // ---- the whole transform on packed fp32 (fft_pk1024.h); same passes, exchanges and tables as below ----
+      using pk::v2f;
+      v2f pv[16];
+      const v2f* win2v = reinterpret_cast<const v2f*>(win_lds);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pv[q] = win2v[t + L * q] * xn[q];
+      SSQ_STAMP(0);
+      SSQ_STAMP(1);
+      pk::dft16(pv);
+      SSQ_STAMP(10);
+      {
+        v2f* ex2 = reinterpret_cast<v2f*>(exch);
+        v2f nv[16];
+        const int rbase = 9 * (t >> 4) + (t & 7);
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) ex2[9 * t + u] = pv[8 * ph + u];
+          frame_sync<false>();
+          if (((t >> 3) & 1) == ph) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nv[q] = ex2[rbase + 36 * q];
+          }
+          frame_sync<false>();
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pv[q] = nv[q];
+      }
+      SSQ_STAMP(11);
+      if (has_next && !SSQ_ABL(32)) load_frame(nsig, tile_frame0(njt), xn);
+      pk::pass1(pv, reinterpret_cast<const v2f*>(tw1), t);
+      SSQ_STAMP(12);
+#pragma unroll
+      for (int uh = 0; uh < 4; ++uh) {
+        float x0 = pv[4 * uh].x, x1 = pv[4 * uh + 1].x, x2 = pv[4 * uh + 2].x, x3 = pv[4 * uh + 3].x;
+        float y0 = pv[4 * uh].y, y1 = pv[4 * uh + 1].y, y2 = pv[4 * uh + 2].y, y3 = pv[4 * uh + 3].y;
+        rows_transpose4(x0, x1, x2, x3);
+        rows_transpose4(y0, y1, y2, y3);
+        pv[4 * uh] = v2f{x0, y0};
+        pv[4 * uh + 1] = v2f{x1, y1};
+        pv[4 * uh + 2] = v2f{x2, y2};
+        pv[4 * uh + 3] = v2f{x3, y3};
+      }
+      {
+#define SSQ_SWAP(i, j)     \
+  {                        \
+    const v2f t_ = pv[i];  \
+    pv[i] = pv[j];         \
+    pv[j] = t_;            \
+  }
+        SSQ_SWAP(1, 4) SSQ_SWAP(2, 8) SSQ_SWAP(3, 12) SSQ_SWAP(6, 9) SSQ_SWAP(7, 13) SSQ_SWAP(11, 14)
+#undef SSQ_SWAP
+      }
+      SSQ_STAMP(13);
+      pk::pass2(pv, reinterpret_cast<const v2f*>(tw2), t);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = cpx<T>{pv[q].x, pv[q].y};
+    } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const cpx<T> wq = win_lds[t + L * q];
+      v[q] = {xn[q] * wq.x, xn[q] * wq.y};
+    }
+    SSQ_STAMP(0);
 #if !SSQ_LATE_PREFETCH
     if (has_next && !SSQ_ABL(32)) load_frame(nsig, tile_frame0(njt), xn);
 #endif
@@ -1026,6 +1096,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     }
     // ---- pass 2: twiddle W_1024^((t + 64 b) m), four radix-4 butterflies ----
     fft_compute<T, 10, 2, false, false, true>(v, twr_unused, tw2 - 256, t);   // compact index m*256 + j, m = 1..3
+    }
     // lane t now holds Z[t + 64 q]
 
     SSQ_STAMP(2);
@@ -1203,7 +1274,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   if (asym && have_prev) read_out(psig, pframe0);
 #ifdef SSQ_STAMPS
   if (p.stamps && t == 0)
-    for (int i = 0; i < 12; ++i) p.stamps[((long long)blockIdx.x * H::W + fl) * 12 + i] = st_acc[i];
+    for (int i = 0; i < 16; ++i) p.stamps[((long long)blockIdx.x * H::W + fl) * 16 + i] = st_acc[i];
 #endif
 }
 
