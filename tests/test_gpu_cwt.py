@@ -106,9 +106,11 @@ def _check_ssq_cwt(x, tol_w, **kw):
             else:
                 lstep = (f_o[-1] - f_o[0]) / (na - 1)
                 v = (w_g[mism] - f_o[0]) / lstep
-        tie_tol = 1e-6 if x.dtype == np.float64 else 2e-3
+        # fp32 evaluates the bin formula (log2 / divide) in fp32; measured worst distance from a rounding boundary among
+        # the differing elements: 3.6e-6 bins, rate 1.5e-6 (profiles/r03_bin_parity.json) -> bounds ~3x / ~7x that
+        tie_tol = 1e-6 if x.dtype == np.float64 else 1e-5
         assert (np.abs(np.abs(v - np.trunc(v)) - 0.5) < tie_tol).all(), f"{mism.sum()} unexplained"
-        assert mism.mean() <= (1e-4 if x.dtype == np.float64 else 5e-3)
+        assert mism.mean() <= (1e-4 if x.dtype == np.float64 else 1e-5)
     keep = dbg["k"] >= 0
     # scatter: re-accumulate with the kernel's own bins (no dw factor in the CWT path)
     Tx_re = np.zeros_like(Tx_o)

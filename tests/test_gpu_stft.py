@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import ssq_oracle as o
+from tests.helpers.binrule import end_to_end_rate, stft_bins_follow_reference_rule
 from ssqueeze_rs_amd import _rs
 
 pytestmark = pytest.mark.gpu
@@ -103,7 +104,7 @@ def _check_ssq_f64(x, win, n_fft, hop, fs, pad, squeezing, gamma=None, win_len=N
     # (|Sx| tiny => w amplifies rounding); everything else must be index-exact
     if mism.any():
         tq = im["w"][mism] / im["dw"]
-        near_tie = np.abs(tq - np.floor(tq) - 0.5) < 1e-6
+        near_tie = np.abs(tq - np.floor(tq) - 0.5) < 1e-9 * np.maximum(1.0, np.abs(tq))
         tiny = np.abs(im["Sx"][mism]) <= 1e-6 * smax
         assert (near_tie | tiny).all(), f"{mism.sum()} unexplained bin mismatches"
     assert mism.mean() <= 1e-3
@@ -149,15 +150,18 @@ def _check_ssq_f32(x32, win, n_fft, hop, fs, pad="reflect", squeezing="sum"):
     assert Tx.dtype == np.complex64 and Tx.shape == Tx_o.shape
     assert np.array_equal(f, f_o)
     smax = np.abs(im["Sx"]).max()
-    assert np.abs(dbg["Sx"] - im["Sx"]).max() <= 4e-6 * smax
-    assert np.abs(dbg["dSx"] - im["dSx"]).max() <= 6e-6 * np.abs(im["dSx"]).max()
+    assert np.abs(dbg["Sx"] - im["Sx"]).max() <= 2e-6 * smax             # SURVEY 8(c); measured 1.0-1.5e-7
+    assert np.abs(dbg["dSx"] - im["dSx"]).max() <= 2e-6 * np.abs(im["dSx"]).max()
     keep_g = dbg["k"] >= 0
     # (a) w: the kernel's own Sx/dSx through the reference formula
     Sg, dSg = dbg["Sx"].astype(np.complex128), dbg["dSx"].astype(np.complex128)
     w_m = o.phase_stft(Sg, dSg, im["Sfs"], o.DEFAULT_GAMMA)
     strong = keep_g & (np.abs(Sg) > 1e-3 * smax) & np.isfinite(w_m)
-    assert np.abs(dbg["w"][strong] - w_m[strong]).max() <= 2e-4 * (0.5 * fs)
-    # (b) index-exact: k == fp32 bin model of the kernel's own w
+    assert np.abs(dbg["w"][strong] - w_m[strong]).max() <= 1e-6 * (0.5 * fs)   # measured 3e-8 .. 1.3e-7
+    # (b) index-exact under the REFERENCE's rule (ssq_stft.rs:280-289, first-minimum scan) given the kernel's own w,
+    #     outside a 2^-22-relative window around half-bin ties (tests/helpers/binrule.py; measured: 0 differences)
+    stft_bins_follow_reference_rule(dbg["k"], dbg["w"], f, keep_g)
+    # (b') and equal to the documented fp32 bin formula everywhere (ties included)
     k_model = o.stft_bins_f32_model(dbg["w"][keep_g], im["dw"], Tx.shape[0])
     assert np.array_equal(dbg["k"][keep_g], k_model)
     # (c) the scatter: re-accumulate from the kernel's own Sx and k
@@ -170,9 +174,11 @@ def _check_ssq_f32(x32, win, n_fft, hop, fs, pad="reflect", squeezing="sum"):
     # (d) end-to-end against the fp64 oracle: per-column energy moves at most between neighbours
     keep_o = ~np.isinf(im["w"])
     both = keep_o & keep_g & (np.abs(im["Sx"]) > 1e-3 * smax)
-    rate = (dbg["k"][both] != im["k"][both]).mean()
-    assert rate <= 0.02, f"fp32 end-to-end bin mismatch rate {rate:.4f}"
-    assert np.abs(dbg["k"][both] - im["k"][both]).max() <= 1
+    # measured (profiles/r03_bin_parity.json): 0 at these sizes, 2.4e-5 at 2^18, 1.3e-5 at C2 -- bound = 2x the worst,
+    # or two bins where the case is too small for the rate to resolve
+    rate = end_to_end_rate(dbg["k"], im["k"], both)
+    assert rate <= max(5e-5, 2.0 / max(1, int(both.sum()))), f"fp32 end-to-end bin mismatch rate {rate:.2e}"
+    assert np.abs(dbg["k"][both] - im["k"][both]).max(initial=0) <= 1
     return rate
 
 
@@ -239,10 +245,17 @@ def test_ssq_stft_full_size_properties():
     assert np.abs(lhs - rhs).max() <= 1e-4 * scale
     k_model = o.stft_bins_f32_model(dbg["w"][keep], dw, 513)
     assert np.array_equal(dbg["k"][keep], k_model)
+    # the reference's first-minimum scan on the kernel's own w: index-exact outside the 2^-22 tie window, 2.1 M bins
+    stft_bins_follow_reference_rule(dbg["k"], dbg["w"], f, keep)
     # and against the fp64 oracle on the same input
     Tx_o, _, im = o.ssq_stft(x.astype(np.float64), win, n_fft=1024, hop_len=256, fs=1.0,
                              return_intermediates=True)
-    assert np.abs(dbg["Sx"] - im["Sx"]).max() <= 4e-6 * np.abs(im["Sx"]).max()
+    assert np.abs(dbg["Sx"] - im["Sx"]).max() <= 2e-6 * np.abs(im["Sx"]).max()
+    smax = np.abs(im["Sx"]).max()
+    both = ~np.isinf(im["w"]) & keep & (np.abs(im["Sx"]) > 1e-3 * smax)
+    rate = end_to_end_rate(dbg["k"], im["k"], both)        # measured 1.3e-5 (profiles/r03_bin_parity.json)
+    assert rate <= 5e-5, f"C2 end-to-end fp32 bin mismatch rate {rate:.2e}"
+    assert np.abs(dbg["k"][both] - im["k"][both]).max() <= 1
     assert np.abs(Tx.sum(0) - Tx_o.sum(0)).max() <= 1e-4 * scale
     # row-energy profile (where the ridges are) agrees
     e_g, e_o = np.abs(Tx).sum(1), np.abs(Tx_o).sum(1)

@@ -17,6 +17,7 @@ import numpy as np
 import pytest
 
 from oracle import ssq_oracle as o
+from tests.helpers.binrule import end_to_end_rate, stft_bins_follow_reference_rule
 from ssqueeze_rs_amd import _lib, _rs
 from ssqueeze_rs_amd.batch import SsqStftBatch
 
@@ -37,9 +38,11 @@ def _check_sig_vs_oracle_f32(x32, win, n_fft, hop, Tx, Sx, w, k, squeezing="sum"
     Tx_o, f_o, im = o.ssq_stft(x32.astype(np.float64), win, n_fft=n_fft, hop_len=hop, fs=1.0,
                                squeezing=squeezing, return_intermediates=True)
     smax = np.abs(im["Sx"]).max()
-    assert np.abs(Sx - im["Sx"]).max() <= 4e-6 * smax
+    assert np.abs(Sx - im["Sx"]).max() <= 2e-6 * smax
     keep = k >= 0
-    # index-exact on the hot kernel's own w
+    # index-exact on the hot kernel's own w: under the reference's scan (ssq_stft.rs:280-289) outside the 2^-22 tie
+    # window, and equal to the documented fp32 formula everywhere
+    stft_bins_follow_reference_rule(k, w, f_o, keep)
     assert np.array_equal(k[keep], o.stft_bins_f32_model(w[keep], im["dw"], Tx.shape[0]))
     # strict scatter check: re-accumulate from the kernel's Sx and the Tx kernel's own k
     Tx_re = o.accumulate_tx(Sx.astype(np.complex128), np.where(keep, k, 0), keep, float(np.float32(im["dw"])),
@@ -49,7 +52,8 @@ def _check_sig_vs_oracle_f32(x32, win, n_fft, hop, Tx, Sx, w, k, squeezing="sum"
     # end to end against the fp64 oracle: bins move at most to a neighbour, rarely
     keep_o = ~np.isinf(im["w"])
     both = keep_o & keep & (np.abs(im["Sx"]) > 1e-3 * smax)
-    assert (k[both] != im["k"][both]).mean() <= 0.02
+    rate = end_to_end_rate(k, im["k"], both)               # measured 2.4e-5 at 2^18 (profiles/r03_bin_parity.json)
+    assert rate <= max(5e-5, 2.0 / max(1, int(both.sum()))), f"end-to-end fp32 bin mismatch rate {rate:.2e}"
     assert np.abs(k[both] - im["k"][both]).max() <= 1
     assert np.abs(Tx.astype(np.complex128).sum(0) - Tx_o.sum(0)).max() <= 1e-4 * smax * im["dw"]
 
@@ -149,8 +153,10 @@ def test_c3_per_gpu_share_32x2pow20_vs_c2_checksums(monkeypatch):
         w, k = _wk(WK[0])
         keep = k >= 0
         assert np.array_equal(k[keep], o.stft_bins_f32_model(w[keep], dw, 513))
+        stft_bins_follow_reference_rule(k, w, o.stft_ssq_freqs(513, 1.0), keep)     # ssq_stft.rs:280-289 on own w
         hist = np.bincount(k[keep].ravel(), minlength=513)
-        assert np.abs(hist - g["k_hist"]).sum() <= 0.04 * g["k_hist"].sum()
+        # measured 1.1e-3 of the bins (all kept bins, weak ones included; profiles/r03_bin_parity.json: 5.4e-4 flip)
+        assert np.abs(hist - g["k_hist"]).sum() <= 4e-3 * g["k_hist"].sum()
         # size-independent invariant on every signal: column sums = dw * sum of the kept Sx (needs Sx: 4 signals)
         SX = eng.run(x[:4], _lib.OUT_SX)
         WK4 = eng.run(x[:4], _lib.OUT_WK)
