@@ -35,6 +35,12 @@ enum { SSQ_SQUEEZE_SUM = 0, SSQ_SQUEEZE_LEBESGUE = 1 };  /* ssq_stft.rs:292-296,
 enum { SSQ_WAVELET_GMW = 0, SSQ_WAVELET_MORLET = 1 };    /* cwt.rs:496-543 */
 enum { SSQ_FREQS_LOG = 0, SSQ_FREQS_LINEAR = 1 };        /* ssq_cwt.rs:56-112 */
 enum { SSQ_MAPRANGE_PEAK = 0, SSQ_MAPRANGE_MAXIMAL = 1 };/* ssq_cwt.rs:450-461 */
+/* numerics variant of a plan / host call (bit flags).  0 = the Rust reference (rust/src/spectral/ *.rs).
+ * SSQ_VARIANT_UPSTREAM = the vendored upstream ssqueezepy the Rust crate was derived from (SURVEY 8(f)-4,
+ * /root/reference/old/ssqueezepy): pad split, Nyquist-zeroed diff-window, np.linspace frequencies, clamped
+ * round-half-even bins, |.| > gamma, normalised wavelets with a halved Nyquist bin, p2up padding, ln2/nv constant.
+ * MODULATED (STFT family, _stft.py:127-147) and FLIPUD (ssqueezing.py: k -> n-1-k) qualify UPSTREAM. */
+enum { SSQ_VARIANT_RUST = 0, SSQ_VARIANT_UPSTREAM = 1, SSQ_VARIANT_MODULATED = 2, SSQ_VARIANT_FLIPUD = 4 };
 /* what a STFT-family plan writes to its output */
 enum {
   SSQ_OUT_TX  = 0,   /* synchrosqueezed STFT            (ssq_stft.rs:270-301) */
@@ -117,6 +123,48 @@ int ssq_gmw_freq(int64_t n, double scale, double gamma, double beta, const char*
 int ssq_gmw_time(int64_t n, double scale, double gamma, double beta, const char* norm, int order, double* out);
 int ssq_gmw_center_frequency(double gamma, double beta, const char* kind, double* out);
 
+/* ---- upstream-parity mode and the inverses (/root/reference/old/ssqueezepy) ---------------------
+ * ssqueezepy.stft      old/ssqueezepy/_stft.py:13-193  (window already n_fft long: get_window, :257-309, is host logic
+ *                      of the Python mirror).  Sx, dSx: [batch][n_fft/2+1][(N-1)/hop+1]; dSx may be NULL. */
+int ssq_stft_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window, int64_t n_fft,
+                    int64_t hop, double fs, int padtype, int variant, void* Sx, void* dSx);
+/* ssqueezepy.ssq_stft  old/ssqueezepy/_ssq_stft.py:12-137 + algos.py:957-968.  gamma < 0: 10 eps of the dtype.
+ * Sx, dSx, wk may be NULL; ssq_freqs: [n_freqs] (reversed with SSQ_VARIANT_FLIPUD). */
+int ssq_ssq_stft_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window, int64_t n_fft,
+                        int64_t hop, double fs, int padtype, int squeezing, double gamma, int variant, void* Tx,
+                        double* ssq_freqs, void* Sx, void* dSx, void* wk);
+/* ssqueezepy.istft     old/ssqueezepy/_stft.py:196-254 (+ utils/stft_utils.py:141-191): per-frame inverse real FFT,
+ * fftshift when modulated, windowed overlap-add, division by the window norm, unpadding.
+ * Sx: [n_fft/2+1][n_frames] complex of `dtype`; window: [n_fft]; x_out: [N] real of `dtype`. */
+int ssq_istft_host(int dtype, const void* Sx, int64_t n_frames, const double* window, int64_t n_fft, int64_t hop,
+                   int64_t n_signal, int modulated, int win_exp, void* x_out);
+/* ssqueezepy.issq_stft / issq_cwt, full inverse (_ssq_stft.py:139-198, _ssq_cwt.py:313-378):
+ * x_out[j] = scale * sum_rows row_scale[row] * Re Tx[row][j]   (scale = 2 / window[n_fft/2]  resp.  2 / adm_ssq;
+ * row_scale NULL = 1; the one-integral icwt of _cwt.py:477-492 is the same sum with 1/sqrt(a) rows for the L2 norm).
+ * Tx: [rows][cols] complex of `dtype`; x_out: [cols] real of `dtype`. */
+int ssq_issq_host(int dtype, const void* Tx, int64_t rows, int64_t cols, double scale, const double* row_scale,
+                  void* x_out);
+/* upstream wavelets: SSQ_WAVELET_GMW with (p0, p1) = (gamma, beta), L1 / bandpass norm (_gmw.py:187-210);
+ * SSQ_WAVELET_MORLET with p0 = mu (wavelets.py:497-523).
+ * adm_ssq = int_0^inf conj(psih(w)) / w dw, adm_cwt = int |psih|^2 / w (utils/cwt_utils.py:28-63, trapezoid on the
+ * grids of integrate_analytic, :583-627); the peak centre frequency on the padded grid (wavelets.py:713-716). */
+int ssq_upstream_adm(int wavelet, double p0, double p1, int which_cwt, double* out);
+int ssq_upstream_center_frequency(int wavelet, double p0, double p1, double scale, int64_t n_padded, double* wc);
+/* utils/common.py:32-51: padded length 2^(1 + round(log2 n)), left pad n1 >= right pad n2 */
+int ssq_upstream_p2up(int64_t n_signal, int64_t* n_up, int64_t* n1, int64_t* n2);
+/* ssqueezepy.cwt       old/ssqueezepy/_cwt.py:12-318 with explicit scales.  Wx, dWx: [batch][na][cols],
+ * cols = rpadded ? n_up : N; dWx may be NULL. */
+int ssq_cwt_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, double p0, double p1,
+                   const double* scales, int64_t na, double dt, int l1_norm, int padtype, int rpadded, int variant,
+                   void* Wx, void* dWx);
+/* ssqueezepy.ssq_cwt   old/ssqueezepy/_ssq_cwt.py:12-311 + ssqueezing.py:122-146 + algos.py:899-910 (exponential
+ * scales, difftype 'trig').  ssq_freqs_asc: [na] the ascending frequencies the bins refer to (the caller reverses
+ * them like ssqueezing.py:199-205); nv: voices per octave of `scales` (the constant ln2/nv).
+ * Wx, dWx, wk may be NULL. */
+int ssq_ssq_cwt_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, double p0, double p1,
+                       const double* scales, int64_t na, double dt, int nv, const double* ssq_freqs_asc, int freq_dist,
+                       int padtype, int squeezing, double gamma, int variant, void* Tx, void* Wx, void* dWx, void* wk);
+
 /* ---- plans: device-resident batch pipelines -------------------------------- */
 typedef struct ssq_stft_plan ssq_stft_plan;
 /* One plan = one (dtype, N, n_fft, hop, window, fs, padtype, squeezing, gamma) configuration.
@@ -124,6 +172,10 @@ typedef struct ssq_stft_plan ssq_stft_plan;
 int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal,
                          const double* window, int64_t n_fft, int64_t hop, double fs,
                          int padtype, int squeezing, double gamma, int force_generic);
+/* the same with a numerics variant (SSQ_VARIANT_*); upstream plans run on the unfused kernels */
+int ssq_stft_plan_create_v(ssq_stft_plan** plan, int dtype, int64_t n_signal,
+                           const double* window, int64_t n_fft, int64_t hop, double fs,
+                           int padtype, int squeezing, double gamma, int force_generic, int variant);
 int ssq_stft_plan_destroy(ssq_stft_plan* plan);
 /* 1 if the fused LDS-tile kernel serves this plan, 0 if the generic kernels do */
 int ssq_stft_plan_is_fused(const ssq_stft_plan* plan);
@@ -158,6 +210,10 @@ int ssq_chunks_relayout(int dtype, const void* d_in, int64_t channels, int64_t c
 typedef struct ssq_cwt_plan ssq_cwt_plan;
 int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet,
                         const double* scales, int64_t na, double dt, int padtype);
+/* the same with a numerics variant (SSQ_VARIANT_*) and the upstream wavelet's parameters (p0, p1) = (gamma, beta) of
+ * the GMW or (mu, -) of the Morlet wavelet; upstream plans pad by p2up and run on the generic transforms */
+int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet, double p0, double p1,
+                          const double* scales, int64_t na, double dt, int padtype, int variant);
 int ssq_cwt_plan_destroy(ssq_cwt_plan* plan);
 int64_t ssq_cwt_plan_workspace_bytes(const ssq_cwt_plan* plan, int64_t batch);
 /* cwt: d_Wx/d_dWx [batch][na][cols]; d_dWx may be NULL */

@@ -62,6 +62,22 @@ _SIGNATURES = {
     "ssq_gmw_center_frequency": (C.c_int, [C.c_double, C.c_double, C.c_char_p, C.POINTER(C.c_double)]),
     "ssq_stft_plan_create": (C.c_int, [C.POINTER(vp), C.c_int, i64, vp, i64, i64, C.c_double, C.c_int,
                                        C.c_int, C.c_double, C.c_int]),
+    "ssq_stft_plan_create_v": (C.c_int, [C.POINTER(vp), C.c_int, i64, vp, i64, i64, C.c_double, C.c_int,
+                                         C.c_int, C.c_double, C.c_int, C.c_int]),
+    "ssq_stft_host_v": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, i64, C.c_double, C.c_int, C.c_int, vp, vp]),
+    "ssq_ssq_stft_host_v": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, i64, C.c_double, C.c_int, C.c_int, C.c_double,
+                                      C.c_int, vp, vp, vp, vp, vp]),
+    "ssq_istft_host": (C.c_int, [C.c_int, vp, i64, vp, i64, i64, i64, C.c_int, C.c_int, vp]),
+    "ssq_issq_host": (C.c_int, [C.c_int, vp, i64, i64, C.c_double, vp, vp]),
+    "ssq_upstream_adm": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),
+    "ssq_upstream_center_frequency": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, i64, C.POINTER(C.c_double)]),
+    "ssq_upstream_p2up": (C.c_int, [i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ssq_cwt_host_v": (C.c_int, [C.c_int, vp, i64, i64, C.c_int, C.c_double, C.c_double, vp, i64, C.c_double, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ssq_ssq_cwt_host_v": (C.c_int, [C.c_int, vp, i64, i64, C.c_int, C.c_double, C.c_double, vp, i64, C.c_double, C.c_int,
+                                     vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]),
+    "ssq_cwt_plan_create_v": (C.c_int, [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_double, C.c_double, vp, i64,
+                                        C.c_double, C.c_int, C.c_int]),
     "ssq_stft_plan_destroy": (C.c_int, [vp]),
     "ssq_stft_plan_is_fused": (C.c_int, [vp]),
     "ssq_stft_plan_workspace_bytes": (i64, [vp, i64, C.c_int]),

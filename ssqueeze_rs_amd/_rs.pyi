@@ -108,3 +108,8 @@ def gmw_freq(n: int = 1024, scale: float = 1.0, gamma: float = 3.0, beta: float 
 def gmw_time(n: int = 1024, scale: float = 1.0, gamma: float = 3.0, beta: float = 60.0, norm: str = "bandpass",
              order: int = 0, dtype: str = "float64") -> NDArray[np.complex128]: ...
 def gmw_center_frequency(gamma: float = 3.0, beta: float = 60.0, kind: str = "peak") -> float: ...
+
+# Private switches of this mirror (not in the reference): `_debug=True` on ssq_stft / ssq_cwt returns the kernels' own
+# intermediates; `_upstream=True` on stft / ssq_stft / cwt / ssq_cwt runs the numerics of the vendored upstream
+# ssqueezepy.  `ssqueeze_rs_amd.upstream` mirrors upstream's own signatures and adds the inverses
+# istft / issq_stft / icwt / issq_cwt.

@@ -23,6 +23,13 @@ struct ssq_cwt_plan {
   bool two_step = false, naive = false;
   bool big = false;            // P > 2^24: batched generic device FFT instead of the tile transforms
   int wavelet = 0, padtype = 0, na = 0;
+  // upstream-parity mode (SSQ_VARIANT_UPSTREAM; old/ssqueezepy): p2up padding, normalised wavelets (wavelet table codes
+  // 2 = GMW(gamma = wp0, beta = wp1), 3 = Morlet(mu = wp0)) with a halved Nyquist bin, the generic transforms only.
+  // ups_freqs / ups_nv: the ascending frequencies and the voices per octave the next ssq exec bins with.
+  int variant = 0, table_code = 0;
+  double wp0 = 0.0, wp1 = 0.0;
+  std::vector<double> ups_freqs;
+  int ups_nv = 0;
   double dt = 1.0;
   std::vector<double> scales;
   void* d_psih = nullptr;      // wavelet table: scale s at psi_off[s], band[s] entries of T (zero beyond: not stored)
@@ -116,6 +123,21 @@ double wavelet_support(int wavelet, int dtype) {
   return dtype == SSQ_F32 ? 6.5 : 10.0;
 }
 
+// the same bound for the upstream wavelets (codes 2, 3 of wavelet_table_kernel): scan upward from the peak until the
+// value rounds to zero in T
+double upstream_support(int wavelet, double p0, double p1, int dtype) {
+  if (wavelet == SSQ_WAVELET_MORLET) return p0 + (dtype == SSQ_F32 ? 15.0 : 39.5);   // exp(-(w - mu)^2 / 2) underflows
+  const double wc = std::exp((1.0 / p0) * (std::log(p1) - std::log(p0)));
+  const double c0 = -p1 * std::log(wc) + std::pow(wc, p0);
+  const double lim = dtype == SSQ_F32 ? -104.0 : -746.0;                             // ln of the smallest denormal
+  double w = wc;
+  for (int it = 0; it < 100000; ++it) {
+    w += 0.01 * wc;
+    if (c0 + p1 * std::log(w) - std::pow(w, p0) < lim) break;
+  }
+  return w;
+}
+
 template <typename T>
 int upload_tw(void** dst, long long n, long long P_total, long long stride) {
   // dst[i] = exp(-2*pi*i * (i*stride) / P_total), i in [0, n)
@@ -197,7 +219,7 @@ int build_tables(ssq_cwt_plan* pl) {
   SSQ_HIP(hipMemcpy(pl->d_psi_off, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice));
   if (pl->na > 0) {
     SSQ_HIP(launch_wavelet_table<T>((T*)pl->d_psih, pl->d_psi_off, pl->d_band, max_band, pl->d_scales, pl->na, pl->P,
-                                    pl->wavelet, nullptr));
+                                    pl->variant ? pl->table_code : pl->wavelet, nullptr, pl->wp0, pl->wp1));
     SSQ_HIP(hipDeviceSynchronize());
   }
   if constexpr (sizeof(T) == 4) {
@@ -614,15 +636,31 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
                    void* d_dbg_wk, char* ws, hipStream_t st) {
   const WsLayout L = ws_layout(pl);
   std::vector<double> f((size_t)pl->na);
-  if (int rc = ssq_cwt_ssq_freqs(pl->scales.data(), pl->na, pl->N, pl->dt, maprange, freq_dist, f.data()))
+  const bool ups = pl->variant != 0;
+  if (ups) {
+    if ((int)pl->ups_freqs.size() != pl->na || pl->ups_nv < 1) SSQ_FAIL("upstream ssq exec: frequencies / nv not set");
+    f = pl->ups_freqs;
+  } else if (int rc = ssq_cwt_ssq_freqs(pl->scales.data(), pl->na, pl->N, pl->dt, maprange, freq_dist, f.data())) {
     return rc;
+  }
   const int n = pl->na;
   CwtSsqDev<T> q;
   std::memset(&q, 0, sizeof(q));
   q.N = pl->N;
   q.na = n;
   q.is_log = (n > 1 && (f[1] / f[0] > 1.1)) ? 1 : 0;                      // ssq_cwt.rs:135-139
-  if (q.is_log) {                                                         // :142-149
+  if (ups) {
+    // old/ssqueezepy/algos.py:356-363 (log: vlmin = log2 v[0], dvl = log2 v[1] - log2 v[0]) and :87-90 (linear)
+    if (n < 2) SSQ_FAIL("upstream ssq_cwt needs at least 2 scales");
+    q.is_log = freq_dist == SSQ_FREQS_LOG ? 1 : 0;
+    const double vmin = q.is_log ? std::log2(f[0]) : f[0];
+    const double dv = q.is_log ? std::log2(f[1]) - std::log2(f[0]) : f[1] - f[0];
+    q.bin_min = (T)vmin;
+    q.bin_step = (T)dv;
+    q.inv_bin_step = (T)(1.0 / dv);
+    q.variant = 1;
+    q.tx_const = (T)(std::log(2.0) / (double)pl->ups_nv);                // ssqueezing.py:122-124
+  } else if (q.is_log) {                                                  // :142-149
     const double lmin = std::log2(f[0]);
     const double lstep = n > 1 ? (std::log2(f[n - 1]) - lmin) / (double)(n - 1) : 1.0;
     q.bin_min = (T)lmin;
@@ -638,9 +676,10 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   q.squeezing = squeezing;
   q.flipud = flipud;
   q.gamma = (T)(gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma);       // ssq_cwt.rs:438-441
+  if (ups && gamma < 0) q.gamma = (T)(10.0 * (sizeof(T) == 8 ? 2.2204460492503131e-16 : 1.1920928955078125e-07));
   q.leb_val = (T)(1.0 / (double)n);
   const long long plane = (long long)n * pl->N;
-  if (pl->fused_ssq() && !pl->all_tiled) {
+  if (pl->fused_ssq() && !pl->all_tiled && !ups) {
     if (!pl->side) {
       SSQ_HIP(hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking));
       SSQ_HIP(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
@@ -669,7 +708,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
     }
     return 0;
   }
-  const int group = (pl->can_fuse_ssq() && !pl->all_tiled) ? ssq_group_env(0) : 0;
+  const int group = (pl->can_fuse_ssq() && !pl->all_tiled && !ups) ? ssq_group_env(0) : 0;
   // reassignment with a written-rows bitmap (first run of a row: plain store).  SSQ_CWT_SWEEP: 0 = read-modify-write
   // of a cleared Tx; 1 (default) = bitmap, Tx cleared beside the transforms; 2 = bitmap and the kernel writes the
   // untouched rows as zeros itself, no clear (measured slower on C4: the clear overlaps the transforms, the zero rows
@@ -677,7 +716,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   const char* sweep_env = std::getenv("SSQ_CWT_SWEEP");
   const int sweep_mode = sweep_env ? std::atoi(sweep_env) : 1;
   const bool os = sizeof(T) == 4 && group == 0 && (pl->os_s1 > pl->os_s0 || pl->os_z1 > pl->os_z0);   // time-tile family
-  const bool sweep = !os && group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
+  const bool sweep = !ups && !os && group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
   const bool self_zero = sweep && (sweep_mode == 2 || !pl->can_fuse_ssq());
   const bool side_clear = pl->can_fuse_ssq() && !self_zero;   // clear Tx beside the transforms
   if (side_clear && !pl->side) {
@@ -825,6 +864,11 @@ extern "C" {
 
 int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet, const double* scales,
                         int64_t na, double dt, int padtype) {
+  return ssq_cwt_plan_create_v(plan, dtype, n_signal, wavelet, 0.0, 0.0, scales, na, dt, padtype, SSQ_VARIANT_RUST);
+}
+
+int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wavelet, double p0, double p1,
+                          const double* scales, int64_t na, double dt, int padtype, int variant) {
   if (!plan) SSQ_FAIL("plan is NULL");
   *plan = nullptr;
   if (dtype != SSQ_F32 && dtype != SSQ_F64) SSQ_FAIL("dtype must be SSQ_F32 or SSQ_F64");
@@ -836,6 +880,25 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   pl->N = n_signal;
   pl->P = host::next_power_of_2(n_signal + n_signal / 2);        // cwt.rs:87
   pl->n1 = (pl->P - pl->N) / 2;                                  // cwt.rs:98
+  const bool ups = (variant & SSQ_VARIANT_UPSTREAM) != 0;
+  if (ups) {
+    int64_t up = 0, n1 = 0, n2 = 0;
+    host::p2up(n_signal, &up, &n1, &n2);                         // old/ssqueezepy/utils/common.py:32-51
+    pl->P = up;
+    pl->n1 = n1;
+    pl->variant = variant;
+    pl->table_code = wavelet == SSQ_WAVELET_MORLET ? 3 : 2;
+    pl->wp0 = p0;
+    pl->wp1 = p1;
+    if (wavelet == SSQ_WAVELET_MORLET && !(p0 > 0.0)) {
+      delete pl;
+      SSQ_FAIL("upstream morlet needs mu > 0");
+    }
+    if (wavelet != SSQ_WAVELET_MORLET && !(p0 > 0.0 && p1 > 0.0)) {
+      delete pl;
+      SSQ_FAIL("upstream gmw needs gamma > 0 and beta > 0");
+    }
+  }
   pl->wavelet = wavelet;
   pl->padtype = padtype;
   pl->na = (int)na;
@@ -869,7 +932,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   // SSQ_CWT_REG=0 keeps the tile kernels for the two-step scales (A/B and tests)
   {
     const char* e = std::getenv("SSQ_CWT_REG");
-    pl->reg = dtype == SSQ_F32 && pl->two_step && (lp == 20 || lp == 21) && !(e && std::atoi(e) == 0);
+    pl->reg = !ups && dtype == SSQ_F32 && pl->two_step && (lp == 20 || lp == 21) && !(e && std::atoi(e) == 0);
     pl->reg_D = pl->reg ? (int)(pl->P >> 20) : 0;
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
@@ -885,7 +948,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   const char* noprune = std::getenv("SSQ_CWT_NOPRUNE");
   if ((pl->two_step || pl->big) && !(noprune && noprune[0] == '1')) {
     const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
-    const double wmax = wavelet_support(wavelet, dtype);
+    const double wmax = ups ? upstream_support(wavelet, p0, p1, dtype) : wavelet_support(wavelet, dtype);
     for (int64_t i = 0; i < na; ++i) {
       const double a = scales[i];
       if (!(a > 0.0) || !std::isfinite(a)) continue;
@@ -902,7 +965,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   // Nyquist frequency (so that the spectrum's cut leaves no slow tail); SSQ_CWT_OS=0 switches it off
   {
     const char* e = std::getenv("SSQ_CWT_OS");
-    if (dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0)) {
+    if (!ups && dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0)) {
       const double sig = wavelet == SSQ_WAVELET_MORLET ? 1.0 : 4.943;
       const double a_hi = (double)kOsHalo / (6.0 * sig);
       const double a_lo = wavelet == SSQ_WAVELET_MORLET ? 4.0 : 1.3;
@@ -961,7 +1024,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int wa
   {
     const char* e = std::getenv("SSQ_CWT_OS");
     const char* ef = std::getenv("SSQ_CWT_OS_FULL");
-    if (dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0) && !(ef && std::atoi(ef) == 0) &&
+    if (!ups && dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0) && !(ef && std::atoi(ef) == 0) &&
         2 * pl->N <= pl->P && n_signal >= 64LL * kOsL) {
       bool ascending = true;
       for (int64_t i = 1; i < na; ++i) ascending = ascending && scales[i] >= scales[i - 1];
@@ -1080,10 +1143,12 @@ struct CwtKey {
   int64_t n_signal;
   double dt;
   std::vector<double> scales;
+  int variant = 0;
+  double p0 = 0.0, p1 = 0.0;
   std::string env = plan_env();
   bool operator==(const CwtKey& o) const {
     return dtype == o.dtype && wavelet == o.wavelet && padtype == o.padtype && n_signal == o.n_signal && dt == o.dt &&
-           scales == o.scales && env == o.env;
+           scales == o.scales && variant == o.variant && p0 == o.p0 && p1 == o.p1 && env == o.env;
   }
 };
 struct CachedCwt {
@@ -1111,8 +1176,8 @@ int cached_cwt_plan(const CwtKey& key, ssq_cwt_plan** out) {
     g_cwt_plans.pop_back();
   }
   ssq_cwt_plan* pl = nullptr;
-  if (int rc = ssq_cwt_plan_create(&pl, key.dtype, key.n_signal, key.wavelet, key.scales.data(),
-                                   (int64_t)key.scales.size(), key.dt, key.padtype))
+  if (int rc = ssq_cwt_plan_create_v(&pl, key.dtype, key.n_signal, key.wavelet, key.p0, key.p1, key.scales.data(),
+                                     (int64_t)key.scales.size(), key.dt, key.padtype, key.variant))
     return rc;
   g_cwt_plans.insert(g_cwt_plans.begin(), CachedCwt{key, pl, dev});
   *out = pl;
@@ -1142,17 +1207,18 @@ void clear_cwt_plans() {
 }  // namespace hostpath
 }  // namespace ssq
 
-extern "C" {
 
-int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, const double* scales,
-                 int64_t na, double dt, int l1_norm, int padtype, int rpadded, void* Wx, void* dWx) {
+static int cwt_host_impl(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, const double* scales,
+                         int64_t na, double dt, int l1_norm, int padtype, int rpadded, void* Wx, void* dWx, int variant,
+                         double p0, double p1) {
   if (!x || !Wx) SSQ_FAIL("x or Wx is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
   if (na == 0) return 0;
   if (!scales) SSQ_FAIL("scales is NULL");
   std::lock_guard<std::mutex> lk(hostpath::mutex());
   ssq_cwt_plan* pl = nullptr;
-  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na)}, &pl))
+  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na), variant,
+                                      p0, p1}, &pl))
     return rc;
   const long long esz = dtype == SSQ_F32 ? 4 : 8;
   const long long cols = rpadded ? pl->P : n_signal;
@@ -1170,19 +1236,22 @@ int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int 
   if (int rc = freed.init()) return rc;
   SSQ_HIP(hipMemcpyAsync(dx, x, (size_t)(batch * in1), hipMemcpyHostToDevice, s0));
   int rc = 0;
-  for (int64_t b = 0; b < batch && rc == 0; ++b) {
+  // one signal: any failure is recorded and the loop left -- both streams are ALWAYS synchronised before returning, the
+  // asynchronous copies write into the caller's (pinned) arrays
+  auto one = [&](int64_t b) -> int {
     const int k = (int)(b & 1);
     char* oW = (char*)dW + (long long)k * out1;
     char* odW = dWx ? (char*)ddW + (long long)k * out1 : nullptr;
     if (b >= 2) SSQ_HIP(hipStreamWaitEvent(s0, freed.ev[k], 0));          // slot k was downloaded
-    rc = ssq_cwt_plan_exec_cwt(pl, (char*)dx + b * in1, 1, l1_norm, rpadded, oW, odW, ws, wsb, s0);
-    if (rc) break;
+    if (int r = ssq_cwt_plan_exec_cwt(pl, (char*)dx + b * in1, 1, l1_norm, rpadded, oW, odW, ws, wsb, s0)) return r;
     SSQ_HIP(hipEventRecord(done.ev[k], s0));
     SSQ_HIP(hipStreamWaitEvent(s1, done.ev[k], 0));
     SSQ_HIP(hipMemcpyAsync((char*)Wx + b * out1, oW, (size_t)out1, hipMemcpyDeviceToHost, s1));
     if (dWx) SSQ_HIP(hipMemcpyAsync((char*)dWx + b * out1, odW, (size_t)out1, hipMemcpyDeviceToHost, s1));
     SSQ_HIP(hipEventRecord(freed.ev[k], s1));
-  }
+    return 0;
+  };
+  for (int64_t b = 0; b < batch && rc == 0; ++b) rc = one(b);
   const hipError_t e0 = hipStreamSynchronize(s0), e1 = hipStreamSynchronize(s1);
   if (rc) return rc;
   SSQ_HIP(e0);
@@ -1190,18 +1259,42 @@ int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int 
   return 0;
 }
 
-int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet,
-                     const double* scales, int64_t na, double dt, int freq_dist, int maprange, int padtype,
-                     int squeezing, int flipud, double gamma, void* Tx, double* ssq_freqs, void* dbg_Wx,
-                     void* dbg_dWx, void* dbg_wk) {
+extern "C" {
+
+int ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, const double* scales,
+                 int64_t na, double dt, int l1_norm, int padtype, int rpadded, void* Wx, void* dWx) {
+  return cwt_host_impl(dtype, x, batch, n_signal, wavelet, scales, na, dt, l1_norm, padtype, rpadded, Wx, dWx,
+                       SSQ_VARIANT_RUST, 0.0, 0.0);
+}
+
+int ssq_cwt_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, double p0, double p1,
+                   const double* scales, int64_t na, double dt, int l1_norm, int padtype, int rpadded, int variant,
+                   void* Wx, void* dWx) {
+  return cwt_host_impl(dtype, x, batch, n_signal, wavelet, scales, na, dt, l1_norm, padtype, rpadded, Wx, dWx, variant, p0,
+                       p1);
+}
+
+}  // extern "C"
+
+static int ssq_cwt_host_impl(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet,
+                             const double* scales, int64_t na, double dt, int freq_dist, int maprange, int padtype,
+                             int squeezing, int flipud, double gamma, void* Tx, double* ssq_freqs, void* dbg_Wx,
+                             void* dbg_dWx, void* dbg_wk, int variant, double p0, double p1, const double* ups_freqs,
+                             int ups_nv) {
   if (!x || !Tx) SSQ_FAIL("x or Tx is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
   if (na <= 0) SSQ_FAIL("index out of bounds: scales is empty (ssq_cwt.rs:459)");
   if (!scales) SSQ_FAIL("scales is NULL");
   std::lock_guard<std::mutex> lk(hostpath::mutex());
   ssq_cwt_plan* pl = nullptr;
-  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na)}, &pl))
+  if (int rc = cached_cwt_plan(CwtKey{dtype, wavelet, padtype, n_signal, dt, std::vector<double>(scales, scales + na), variant,
+                                      p0, p1}, &pl))
     return rc;
+  if (variant & SSQ_VARIANT_UPSTREAM) {
+    if (!ups_freqs) SSQ_FAIL("ssq_freqs_asc is NULL");
+    pl->ups_freqs.assign(ups_freqs, ups_freqs + na);
+    pl->ups_nv = ups_nv;
+  }
   const long long esz = dtype == SSQ_F32 ? 4 : 8;
   const long long out1 = na * n_signal * 2 * esz, in1 = n_signal * esz;
   void *dx = nullptr, *dT = nullptr, *d1 = nullptr, *d2 = nullptr, *d3 = nullptr, *ws = nullptr;
@@ -1221,14 +1314,14 @@ int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, 
   if (int rc = freed.init()) return rc;
   SSQ_HIP(hipMemcpyAsync(dx, x, (size_t)(batch * in1), hipMemcpyHostToDevice, s0));
   int rc = 0;
-  for (int64_t b = 0; b < batch && rc == 0; ++b) {
+  auto one = [&](int64_t b) -> int {             // (errors leave the loop; the streams are synchronised below either way)
     const int k = (int)(b & 1);
     const long long so = (long long)k * out1;
     if (b >= 2) SSQ_HIP(hipStreamWaitEvent(s0, freed.ev[k], 0));
-    rc = ssq_cwt_plan_exec_ssq(pl, (char*)dx + b * in1, 1, freq_dist, maprange, squeezing, flipud, gamma, (char*)dT + so,
-                               dbg_Wx ? (char*)d1 + so : nullptr, dbg_dWx ? (char*)d2 + so : nullptr,
-                               dbg_wk ? (char*)d3 + so : nullptr, ws, wsb, s0);
-    if (rc) break;
+    if (int r = ssq_cwt_plan_exec_ssq(pl, (char*)dx + b * in1, 1, freq_dist, maprange, squeezing, flipud, gamma,
+                                      (char*)dT + so, dbg_Wx ? (char*)d1 + so : nullptr,
+                                      dbg_dWx ? (char*)d2 + so : nullptr, dbg_wk ? (char*)d3 + so : nullptr, ws, wsb, s0))
+      return r;
     SSQ_HIP(hipEventRecord(done.ev[k], s0));
     SSQ_HIP(hipStreamWaitEvent(s1, done.ev[k], 0));
     SSQ_HIP(hipMemcpyAsync((char*)Tx + b * out1, (char*)dT + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
@@ -1236,14 +1329,34 @@ int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, 
     if (dbg_dWx) SSQ_HIP(hipMemcpyAsync((char*)dbg_dWx + b * out1, (char*)d2 + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
     if (dbg_wk) SSQ_HIP(hipMemcpyAsync((char*)dbg_wk + b * out1, (char*)d3 + so, (size_t)out1, hipMemcpyDeviceToHost, s1));
     SSQ_HIP(hipEventRecord(freed.ev[k], s1));
-  }
+    return 0;
+  };
+  for (int64_t b = 0; b < batch && rc == 0; ++b) rc = one(b);
   const hipError_t e0 = hipStreamSynchronize(s0), e1 = hipStreamSynchronize(s1);
   if (rc) return rc;
   SSQ_HIP(e0);
   SSQ_HIP(e1);
-  if (ssq_freqs)
+  if (ssq_freqs && !(variant & SSQ_VARIANT_UPSTREAM))
     if (int rc2 = ssq_cwt_ssq_freqs(scales, na, n_signal, dt, maprange, freq_dist, ssq_freqs)) return rc2;
   return 0;
+}
+
+extern "C" {
+
+int ssq_ssq_cwt_host(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet,
+                     const double* scales, int64_t na, double dt, int freq_dist, int maprange, int padtype,
+                     int squeezing, int flipud, double gamma, void* Tx, double* ssq_freqs, void* dbg_Wx,
+                     void* dbg_dWx, void* dbg_wk) {
+  return ssq_cwt_host_impl(dtype, x, batch, n_signal, wavelet, scales, na, dt, freq_dist, maprange, padtype, squeezing,
+                           flipud, gamma, Tx, ssq_freqs, dbg_Wx, dbg_dWx, dbg_wk, SSQ_VARIANT_RUST, 0.0, 0.0, nullptr, 0);
+}
+
+int ssq_ssq_cwt_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, int wavelet, double p0, double p1,
+                       const double* scales, int64_t na, double dt, int nv, const double* ssq_freqs_asc, int freq_dist,
+                       int padtype, int squeezing, double gamma, int variant, void* Tx, void* Wx, void* dWx, void* wk) {
+  return ssq_cwt_host_impl(dtype, x, batch, n_signal, wavelet, scales, na, dt, freq_dist, SSQ_MAPRANGE_PEAK, padtype,
+                           squeezing, (variant & SSQ_VARIANT_FLIPUD) ? 1 : 0, gamma, Tx, nullptr, Wx, dWx, wk, variant, p0,
+                           p1, ssq_freqs_asc, nv);
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@ struct ssq_stft_plan {
   long long n_signal = 0;
   int n_fft = 0, hop = 0, n_freqs = 0, n_frames = 0, pad_left = 0;
   int padtype = 0, squeezing = 0;
+  int variant = 0, rot = 0;        // upstream-parity mode (SSQ_VARIANT_*), frame rotation of the modulated STFT
   double fs = 1.0, gamma = 0.0;
   bool fused = false;
   bool fft_path = false;           // unfused, but through the batched any-length device FFT instead of direct sums
@@ -140,6 +141,9 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.dw = (T)pl->dw;
   p.inv_dw = (T)(1.0 / pl->dw);
   p.gamma2 = (T)(pl->gamma * pl->gamma);
+  p.gamma = (T)pl->gamma;
+  p.variant = pl->variant;
+  p.rot = pl->rot;
   p.leb_val = (T)((1.0 / (double)pl->n_freqs) * pl->dw);
   p.f_last = (T)pl->ssq_freqs[pl->n_freqs - 1];
   p.inv_alpha = (T)(1.0 / pl->alpha);
@@ -224,6 +228,13 @@ extern "C" {
 int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, const double* window,
                          int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing,
                          double gamma, int force_generic) {
+  return ssq_stft_plan_create_v(plan, dtype, n_signal, window, n_fft, hop, fs, padtype, squeezing, gamma, force_generic,
+                                SSQ_VARIANT_RUST);
+}
+
+int ssq_stft_plan_create_v(ssq_stft_plan** plan, int dtype, int64_t n_signal, const double* window,
+                           int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing,
+                           double gamma, int force_generic, int variant) {
   if (!plan) SSQ_FAIL("plan is NULL");
   *plan = nullptr;
   if (dtype != SSQ_F32 && dtype != SSQ_F64) SSQ_FAIL("dtype must be SSQ_F32 or SSQ_F64");
@@ -244,6 +255,16 @@ int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, cons
   pl->squeezing = squeezing;
   pl->fs = fs;
   pl->gamma = gamma < 0 ? 10.0 * 2.2204460492503131e-16 : gamma;   // ssq_stft.rs:258-261
+  const bool ups = (variant & SSQ_VARIANT_UPSTREAM) != 0;
+  pl->variant = variant;
+  if (ups) {
+    // old/ssqueezepy: padlength N + n_fft - 1 with the LARGER half on the left (utils/common.py:111-116), frames
+    // rotated by n_fft/2 when modulated (utils/stft_utils.py:70-83), gamma = 10 eps of the dtype (_ssq_stft.py:103-104)
+    pl->pad_left = (int)(n_fft / 2);
+    pl->rot = (variant & SSQ_VARIANT_MODULATED) ? (int)(n_fft / 2) : 0;
+    if (gamma < 0) pl->gamma = 10.0 * (dtype == SSQ_F64 ? 2.2204460492503131e-16 : 1.1920928955078125e-07);
+    force_generic = force_generic ? 1 : 2;                   // unfused kernels only (2: through the device FFT)
+  }
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -254,9 +275,16 @@ int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, cons
     pl->ssq_freqs[i] = ((double)i * 0.5 * fs) / ((double)nf - 1.0);          // ssq_stft.rs:50
   pl->dw = nf > 1 ? pl->ssq_freqs[1] - pl->ssq_freqs[0] : 0.0;               // ssq_stft.rs:273
   pl->sfs_step = nf > 1 ? (0.5 * fs - 0.0) / (double)(nf - 1) : 0.0;         // ssq_stft.rs:255 (linspace)
+  if (ups) {                                                                 // Sfs = ssq_freqs = np.linspace(0, fs/2, n)
+    pl->ssq_freqs = host::np_linspace(0.0, 0.5 * fs, nf);                    // _ssq_stft.py:248-257, :117-118
+    pl->dw = nf > 1 ? pl->ssq_freqs[1] - pl->ssq_freqs[0] : 0.0;             // ssqueezing.py:129-130
+  }
   std::vector<double> g(window, window + n_fft);
-  std::vector<double> gd = host::diff_window(g.data(), n_fft);               // ssq_stft.rs:131-179
-  for (auto& v : gd) v *= fs;                                                // ssq_stft.rs:208
+  std::vector<double> gd = host::diff_window(g.data(), n_fft, ups);          // ssq_stft.rs:131-179 | _stft.py:293-299
+  // ssq_stft.rs:208.  Upstream scales the diff-window by fs only inside its `modulated` branch (_stft.py:132-135):
+  // reproduced as written
+  if (!ups || (variant & SSQ_VARIANT_MODULATED))
+    for (auto& v : gd) v *= fs;
   {
     // The fused kernel packs z = x*g + i*x*g'*fs*alpha into one complex FFT.  alpha (a power of
     // two, so exact) makes the two channels the same magnitude: otherwise the small channel
@@ -287,7 +315,7 @@ int ssq_stft_plan_create(ssq_stft_plan** plan, int dtype, int64_t n_signal, cons
   pl->tile_frames = pl->fused ? (f32 ? fused_tile_frames<float>(pl->fft_len) : fused_tile_frames<double>(pl->fft_len)) : 1;
   // everything else that is long enough to matter: the batched any-length device FFT (force_generic keeps the direct
   // sums as the independent second implementation of the parity tests)
-  pl->fft_path = !pl->fused && !force_generic && n_fft >= 24;
+  pl->fft_path = !pl->fused && (force_generic == 0 || force_generic == 2) && n_fft >= 24;
   int rc = f32 ? upload_tables<float>(pl, g, gd) : upload_tables<double>(pl, g, gd);
   if (rc) {
     ssq_stft_plan_destroy(pl);
@@ -362,12 +390,13 @@ int ssq_stft_plan_exec_strided(ssq_stft_plan* pl, int out_kind, const void* d_x,
 namespace {
 
 struct PlanKey {
-  int dtype, padtype, squeezing;
+  int dtype, padtype, squeezing, variant;
   int64_t n_signal, n_fft, hop;
   double fs, gamma;
   std::vector<double> window;
   bool operator==(const PlanKey& o) const {
-    return dtype == o.dtype && padtype == o.padtype && squeezing == o.squeezing && n_signal == o.n_signal &&
+    return dtype == o.dtype && padtype == o.padtype && squeezing == o.squeezing && variant == o.variant &&
+           n_signal == o.n_signal &&
            n_fft == o.n_fft && hop == o.hop && fs == o.fs && gamma == o.gamma && window == o.window;
   }
 };
@@ -392,8 +421,8 @@ int cached_plan(const PlanKey& key, ssq_stft_plan** out) {
     }
   }
   ssq_stft_plan* pl = nullptr;
-  if (int rc = ssq_stft_plan_create(&pl, key.dtype, key.n_signal, key.window.data(), key.n_fft, key.hop, key.fs,
-                                    key.padtype, key.squeezing, key.gamma, 0))
+  if (int rc = ssq_stft_plan_create_v(&pl, key.dtype, key.n_signal, key.window.data(), key.n_fft, key.hop, key.fs,
+                                      key.padtype, key.squeezing, key.gamma, 0, key.variant))
     return rc;
   g_plans.insert(g_plans.begin(), CachedPlan{key, pl, dev});
   while (g_plans.size() > kMaxPlans) {
@@ -421,13 +450,14 @@ void clear_stft_plans() {
 // thread only ever waits for the upload staging of pageable inputs.
 static int run_host(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window,
                     int64_t n_fft, int64_t hop, double fs, int padtype, int squeezing, double gamma,
-                    int n_out, const int* kinds, void* const* outs) {
+                    int n_out, const int* kinds, void* const* outs, int variant = SSQ_VARIANT_RUST) {
   if (!x) SSQ_FAIL("x is NULL");
   if (batch <= 0) SSQ_FAIL("batch must be positive");
   if (!window) SSQ_FAIL("window is NULL");
   if (n_fft <= 0) SSQ_FAIL("n_fft must be positive");
   std::lock_guard<std::mutex> lk(hostpath::mutex());
-  PlanKey key{dtype, padtype, squeezing, n_signal, n_fft, hop, fs, gamma, std::vector<double>(window, window + n_fft)};
+  PlanKey key{dtype, padtype, squeezing, variant, n_signal, n_fft, hop, fs, gamma,
+              std::vector<double>(window, window + n_fft)};
   ssq_stft_plan* pl = nullptr;
   if (int rc = cached_plan(key, &pl)) return rc;
   const int64_t esz = dtype == SSQ_F32 ? 4 : 8;
@@ -500,6 +530,37 @@ int ssq_ssq_stft_host(int dtype, const void* x, int64_t batch, int64_t n_signal,
   if (ssq_freqs) {
     const int64_t nf = n_fft / 2 + 1;
     for (int64_t i = 0; i < nf; ++i) ssq_freqs[i] = ((double)i * 0.5 * fs) / ((double)nf - 1.0);
+  }
+  return 0;
+}
+
+// ---- upstream-parity mode: the same pipeline on the unfused kernels with the variant's numerics ----
+int ssq_stft_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window, int64_t n_fft,
+                    int64_t hop, double fs, int padtype, int variant, void* Sx, void* dSx) {
+  if (!Sx) SSQ_FAIL("Sx is NULL");
+  const int kinds[2] = {SSQ_OUT_SX, SSQ_OUT_DSX};
+  void* outs[2] = {Sx, dSx};
+  return run_host(dtype, x, batch, n_signal, window, n_fft, hop, fs, padtype, 0, -1.0, 2, kinds, outs, variant);
+}
+
+int ssq_ssq_stft_host_v(int dtype, const void* x, int64_t batch, int64_t n_signal, const double* window, int64_t n_fft,
+                        int64_t hop, double fs, int padtype, int squeezing, double gamma, int variant, void* Tx,
+                        double* ssq_freqs, void* Sx, void* dSx, void* wk) {
+  if (!Tx) SSQ_FAIL("Tx is NULL");
+  if (n_fft / 2 + 1 < 2) SSQ_FAIL("ssq_stft needs at least 2 frequency bins");
+  const int kinds[4] = {SSQ_OUT_TX, SSQ_OUT_SX, SSQ_OUT_DSX, SSQ_OUT_WK};
+  void* outs[4] = {Tx, Sx, dSx, wk};
+  if (int rc = run_host(dtype, x, batch, n_signal, window, n_fft, hop, fs, padtype, squeezing, gamma, 4, kinds, outs,
+                        variant))
+    return rc;
+  if (ssq_freqs) {
+    const int64_t nf = n_fft / 2 + 1;
+    if (variant & SSQ_VARIANT_UPSTREAM) {                      // Sfs, reversed with flipud (ssqueezing.py:199-205)
+      const std::vector<double> f = host::np_linspace(0.0, 0.5 * fs, nf);
+      for (int64_t i = 0; i < nf; ++i) ssq_freqs[i] = (variant & SSQ_VARIANT_FLIPUD) ? f[nf - 1 - i] : f[i];
+    } else {
+      for (int64_t i = 0; i < nf; ++i) ssq_freqs[i] = ((double)i * 0.5 * fs) / ((double)nf - 1.0);
+    }
   }
   return 0;
 }

@@ -15,6 +15,19 @@ namespace ssq {
 template <typename T>
 __device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cpx<T> dW, T& w) {
   const T two_pi = (T)(2.0 * 3.14159265358979323846);
+  if (p.variant) {
+    // upstream (old/ssqueezepy/algos.py:899-940), plain arithmetic in T: the normalised wavelets cannot overflow fp32
+    const T A = dW.x, B = dW.y, C = Wv.x, D = Wv.y;
+    if (!(hypot(C, D) > p.gamma)) {
+      w = (T)INFINITY;
+      return -1;
+    }
+    w = fabs((B * C - A * D) / ((C * C + D * D) * (T)6.283185307179586));
+    const T v = fmax(((p.is_log ? log2(w) : w) - p.bin_min) / p.bin_step, (T)0);
+    int bin = (v >= (T)(p.na - 1)) ? p.na - 1 : (int)rint(v);
+    if (!(v == v)) bin = 0;
+    return p.flipud ? (p.na - 1 - bin) : bin;
+  }
   bool small;
   if constexpr (sizeof(T) == 4) {
     // pre-scaled ratio: the reference's GMW is un-normalised (peak ~4e17), so |Wx|^2 and

@@ -55,7 +55,7 @@ int cwt_tile_rows(int logm);
 // where the value is not exactly zero in T is stored (1.07 GB -> 0.2 GB at C4)
 template <typename T>
 hipError_t launch_wavelet_table(T* psih, const long long* d_off, const int* d_band, int max_band, const double* d_scales,
-                                int na, long long P, int wavelet, hipStream_t stream);
+                                int na, long long P, int wavelet, hipStream_t stream, double p0 = 0.0, double p1 = 0.0);
 
 // P > 2^24 (beyond the two-step tile transforms): the same pipeline through the batched any-length device FFT
 // (fft_generic.h, Stockham passes through global memory) -- functional for any length the memory holds, not tuned.
@@ -87,6 +87,10 @@ struct CwtSsqDev {
   T inv_bin_step;        // 1 / bin_step (evaluated in fp64 on the host)
   T gamma;
   T leb_val;             // 1/na                                      (ssq_cwt.rs:201-204)
+  // upstream-parity mode (old/ssqueezepy/algos.py:899-940, ssqueezing.py:122-128): keep |Wx| > gamma,
+  // k = min(rint(max(v, 0)), na-1) (clamped, half to even), every contribution times tx_const (= ln 2 / nv)
+  int variant;
+  T tx_const;
 };
 template <typename T>
 hipError_t launch_cwt_reassign(const CwtSsqDev<T>& p, hipStream_t stream, bool clear);   // clear: zero Tx first

@@ -380,7 +380,8 @@ hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream) {
 // cwt.rs:492-547; evaluated in fp64 for both dtypes, rounded once to T.
 template <typename T>
 __global__ void wavelet_table_kernel(T* __restrict__ psih, const long long* __restrict__ off, const int* __restrict__ band,
-                                     const double* __restrict__ scales, int na, long long P, int wavelet) {
+                                     const double* __restrict__ scales, int na, long long P, int wavelet, double p0,
+                                     double p1) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (s >= na || k >= band[s]) return;
@@ -396,17 +397,29 @@ __global__ void wavelet_table_kernel(T* __restrict__ psih, const long long* __re
       const double wm = w - mu;
       v = norm * (exp(-0.5 * (wm * wm)) - k_exp * exp(-0.5 * (w * w)));
     }
+  } else if (wavelet == 2) {                            // upstream GMW, L1 norm: old/ssqueezepy/_gmw.py:204-210
+    if (w > 0.0) {
+      const double wc = exp((1.0 / p0) * (log(p1) - log(p0)));       // morsefreq, _gmw.py:611-657  (p0 = gamma, p1 = beta)
+      v = 2.0 * exp(-p1 * log(wc) + pow(wc, p0) + p1 * log(w) - pow(w, p0));
+    }
+  } else if (wavelet == 3) {                            // upstream Morlet: old/ssqueezepy/wavelets.py:497-523 (p0 = mu)
+    const double cs = pow(1.0 + exp(-p0 * p0) - 2.0 * exp(-0.75 * p0 * p0), -0.5);
+    const double ks = exp(-0.5 * p0 * p0);
+    v = 1.41421356237309504880 * cs * pow(3.14159265358979323846, 0.25) *
+        (exp(-0.5 * (w - p0) * (w - p0)) - ks * exp(-0.5 * w * w));
   } else {                                              // "gmw" | _  cwt.rs:522-542
     if (w > 0.0) v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
   }
+  if (wavelet >= 2 && 2 * k == P) v *= 0.5;             // upstream halves the Nyquist bin (wavelets.py:87-95)
   psih[off[s] + k] = (T)v;
 }
 
 template <typename T>
 hipError_t launch_wavelet_table(T* psih, const long long* d_off, const int* d_band, int max_band, const double* d_scales,
-                                int na, long long P, int wavelet, hipStream_t stream) {
+                                int na, long long P, int wavelet, hipStream_t stream, double p0, double p1) {
   dim3 grid((unsigned)((max_band + 255) / 256), (unsigned)na, 1);
-  hipLaunchKernelGGL(wavelet_table_kernel<T>, grid, dim3(256), 0, stream, psih, d_off, d_band, d_scales, na, P, wavelet);
+  hipLaunchKernelGGL(wavelet_table_kernel<T>, grid, dim3(256), 0, stream, psih, d_off, d_band, d_scales, na, P, wavelet, p0,
+                     p1);
   return hipGetLastError();
 }
 
@@ -801,7 +814,14 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
         acc = {(T)0, (T)0};
       }
       if (kk >= 0) {
-        if (p.squeezing == 1) {
+        if (p.variant) {                     // upstream: out[k, j] += Wx[i, j] * const  (algos.py:910)
+          if (p.squeezing == 1) {
+            acc.x += p.leb_val * p.tx_const;
+          } else {
+            acc.x += Wv.x * p.tx_const;
+            acc.y += Wv.y * p.tx_const;
+          }
+        } else if (p.squeezing == 1) {
           acc.x += p.leb_val;
         } else {
           acc.x += Wv.x;
@@ -939,7 +959,7 @@ int cwt_tile_rows(int logm) {
   template int cwt_tile_rows<T>(int);                                                                 \
   template hipError_t launch_cwt_tile<T>(int, const CwtDev<T>&, hipStream_t);                         \
   template hipError_t launch_wavelet_table<T>(T*, const long long*, const int*, int, const double*, int, long long, int, \
-                                              hipStream_t);                                          \
+                                              hipStream_t, double, double);                          \
   template hipError_t launch_cwt_naive_fwd<T>(const CwtDev<T>&, hipStream_t);                         \
   template hipError_t launch_cwt_big_fwd<T>(const CwtDev<T>&, cpx<T>*, hipStream_t);                  \
   template hipError_t launch_cwt_big_inv<T>(const CwtDev<T>&, cpx<T>*, hipStream_t);                  \

@@ -111,12 +111,14 @@ inline std::vector<double> size_window(const double* w, int64_t L, int64_t n_fft
   return out;
 }
 
-// ssq_stft.rs:131-179
-inline std::vector<double> diff_window(const double* win, int64_t n) {
+// ssq_stft.rs:131-179; zero_nyquist: the upstream variant (old/ssqueezepy/_stft.py:293-299) drops the Nyquist term of
+// even lengths
+inline std::vector<double> diff_window(const double* win, int64_t n, bool zero_nyquist = false) {
   std::vector<double> freqs((size_t)n);
   for (int64_t i = 0; i < n / 2 + 1 && i < n; ++i) freqs[i] = (double)i;
   for (int64_t i = n / 2 + 1; i < n; ++i) freqs[i] = (double)i - (double)n;
   for (int64_t i = 0; i < n; ++i) freqs[i] *= 2.0 * M_PI / (double)n;
+  if (zero_nyquist && n % 2 == 0 && n > 0) freqs[n / 2] = 0.0;
   std::vector<cd> W((size_t)n);
   for (int64_t i = 0; i < n; ++i) W[i] = cd(win[i], 0.0);
   fft_any(W, -1);
@@ -126,6 +128,26 @@ inline std::vector<double> diff_window(const double* win, int64_t n) {
   const double scale = 1.0 / (double)n;
   for (int64_t i = 0; i < n; ++i) out[i] = W[i].real() * scale;
   return out;
+}
+
+// numpy.linspace(a, b, n) as upstream uses it (old/ssqueezepy/_ssq_stft.py:248-257): arange(n)*step + a, last = b
+inline std::vector<double> np_linspace(double a, double b, int64_t n) {
+  std::vector<double> y((size_t)(n > 0 ? n : 0));
+  if (n == 1) y[0] = a;
+  if (n < 2) return y;
+  const double step = (b - a) / (double)(n - 1);
+  for (int64_t i = 0; i < n; ++i) y[i] = (double)i * step + a;
+  y[n - 1] = b;
+  return y;
+}
+
+// old/ssqueezepy/utils/common.py:32-51: padded length 2^(1 + round(log2 n)) (numpy rounds half to even), left pad the
+// larger half
+inline void p2up(int64_t n, int64_t* up, int64_t* n1, int64_t* n2) {
+  const double r = std::nearbyint(std::log2((double)n));
+  *up = (int64_t)std::llround(std::pow(2.0, 1.0 + r));
+  *n2 = (*up - n) / 2;
+  *n1 = *up - n - *n2;
 }
 
 // utils/array.rs:9-11

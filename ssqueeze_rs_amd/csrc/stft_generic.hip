@@ -22,7 +22,9 @@ __global__ void frames_pack_kernel(StftDev<T> p, long long sig, int n_fft, Gener
   if (j >= n_fft) return;
   const T* xs = sig_base(p, sig);
   const double xv = (double)load_padded(xs, (long long)f * p.hop - p.pad_left + j, p.n_signal, p.padtype);
-  Z[(long long)f * n_fft + j] = {(T)(xv * tabs.g[j]), (T)(xv * tabs.gd[j] * alpha)};
+  int m = j - p.rot;                                       // modulated frames (upstream variant): rotated transform input
+  if (m < 0) m += n_fft;
+  Z[(long long)f * n_fft + m] = {(T)(xv * tabs.g[j]), (T)(xv * tabs.gd[j] * alpha)};
 }
 
 // Z[frame][k] -> Sx[k][frame] = (Z[k] + conj Z[n-k])/2, dSx[k][frame] = (Z[k] - conj Z[n-k])/(2i) / alpha, through a
@@ -79,7 +81,8 @@ __global__ void dft_frames_kernel(StftDev<T> p, int n_fft, GenericTabs tabs, cpx
   const T* xs = sig_base(p, b);
   const long long pos0 = (long long)j * hop - pad_left;
   double sr = 0, si = 0, dr = 0, di = 0;
-  int idx = 0;                                            // (n*k) mod n_fft
+  // (m*k) mod n_fft for the transform input m = (n - rot) mod n_fft of sample n (rot = 0 outside the upstream variant)
+  int idx = (int)(((long long)((n_fft - p.rot) % n_fft) * k) % n_fft);
   for (int n = 0; n < n_fft; ++n) {
     const double xv = (double)load_padded(xs, pos0 + n, n_signal, padtype);
     const double c = tabs.tw_re[idx], s = tabs.tw_im[idx];

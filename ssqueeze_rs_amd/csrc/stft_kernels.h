@@ -44,6 +44,13 @@ struct StftDev {
   // of n_eff samples is transformed through two FFTs of the kernel's own length m = 2^LOGN >= 2*n_eff - 1.
   // win2 then holds (window * chirp) zero-padded to m, blue_b the spectrum of the chirp filter (times 1/m) and
   // blue_post the output chirp exp(-i*pi*k^2/n_eff), k < n_eff.
+  // Upstream-parity mode (/root/reference/old/ssqueezepy; unfused kernels only): variant & 1 switches
+  // the bin rule to algos.py:957-968 (keep |Sx| > gamma; k = min(rint(max((w - f0)/dw, 0)), n-1), half-to-even, with
+  // Sfs read from the table = np.linspace), variant & 4 flips the rows (k = n-1-k); `rot` = n_fft/2 rotates the frame
+  // (modulated STFT: stft_utils.py:70-83) -- sample j of a frame is transform input (j - rot) mod n_fft.
+  int variant;
+  int rot;
+  T gamma;                 // the threshold itself (the upstream rule compares |Sx| > gamma)
   int n_eff;               // n_fft actually transformed (== 2^LOGN outside Bluestein mode)
   const cpx<T>* blue_b;
   const cpx<T>* blue_post;
@@ -96,6 +103,20 @@ hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx
 // ---------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
+  if (p.variant & 1) {
+    // upstream (old/ssqueezepy/algos.py:957-968), evaluated in T like numba does for the array's dtype
+    const T A = dS.x, B = dS.y, C = S.x, D = S.y;
+    const T w = fabs(p.ssq_freqs[i] - (B * C - A * D) / ((C * C + D * D) * (T)6.283185307179586));
+    const bool keep = hypot(C, D) > p.gamma;
+    w_out = keep ? w : (T)INFINITY;
+    const int last = p.n_freqs - 1;
+    const T v = fmax((w - p.ssq_freqs[0]) / p.dw, (T)0);
+    int kk = (v >= (T)last) ? last : (int)rint(v);      // NaN: comparisons false, rint(NaN) -> 0 by the cast below
+    if (!(v == v)) kk = 0;
+    if (p.variant & 4) kk = last - kk;
+    kk_out = kk;
+    return keep;
+  }
   const T den = S.x * S.x + S.y * S.y;
   const T num = dS.y * S.x - dS.x * S.y;
   const T two_pi = p.two_pi_eff;                    // 6.283185307179586 (ssq_stft.rs:32) [* alpha]
