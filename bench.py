@@ -477,20 +477,36 @@ def main():
         nshare = int(cnt.item())
         shard = out_t[: nshare * bins * 2]
         outl = torch.empty(world * shard.numel(), device="cuda", dtype=torch.float32)
-        dist.all_gather_into_tensor(outl, shard)
-        torch.cuda.synchronize()
+        # the gather itself goes through the C-ABI (ssq_gather_shards: RCCL dlopen'd by the library, no torch on the data
+        # path); torch.distributed only carries the 128-byte RCCL id from rank 0 to the others
+        idb = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(lib.ssq_rccl_unique_id(idb))
+        box = [bytes(idb.raw)]
+        dist.broadcast_object_list(box, src=0)
+        idb = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        _lib.check(lib.ssq_rccl_comm_init(C.byref(comm), world, idb, rank))
+        nbytes = int(shard.numel() * 4)
+
+        def do_gather():
+            _lib.check(lib.ssq_gather_shards(comm, C.c_void_p(shard.data_ptr()), C.c_void_p(outl.data_ptr()), nbytes, stream))
+            _lib.check(lib.ssq_stream_sync(stream))
+
+        do_gather()
         dist.barrier()
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(outl, shard)
-        torch.cuda.synchronize()
+        do_gather()
         g_ms = (time.perf_counter() - g0) * 1e3
         mine = outl[rank * shard.numel(): (rank + 1) * shard.numel()]
-        seen = torch.tensor([rank], device="cuda", dtype=torch.int64)
-        ranks = [torch.zeros_like(seen) for _ in range(world)]
-        dist.all_gather(ranks, seen)
-        gather = {"ms": g_ms, "bytes_per_rank": int(shard.numel() * 4), "signals_per_rank": nshare,
+        n_seen, me = C.c_int(0), C.c_int(0)
+        _lib.check(lib.ssq_rccl_comm_info(comm, C.byref(n_seen), C.byref(me)))
+        heads = outl.view(world, -1)[:, :2].clone()         # every rank's first value arrived where its rank says
+        gather = {"ms": g_ms, "bytes_per_rank": nbytes, "signals_per_rank": nshare, "via": "ssq_gather_shards (C-ABI, RCCL)",
                   "own_shard_round_trip_equal": bool(torch.equal(mine, shard)),
-                  "ranks_seen_by_rccl": [int(r.item()) for r in ranks]}
+                  "ranks_seen_by_rccl": int(n_seen.value), "my_rccl_rank": int(me.value),
+                  "shards_nonzero": bool((heads.abs().sum(1) > 0).all().item())}
+        lib.ssq_rccl_comm_destroy(comm)
         del outl
 
     if rank == 0:

@@ -226,6 +226,21 @@ int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* plan, const void* d_x, int64_t batch,
                           void* d_Tx, void* d_dbg_Wx, void* d_dbg_dWx, void* d_dbg_wk,
                           void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- multi-GPU: the optional final gather of the batch-sharded results over xGMI ------------------------------
+ * Signals are independent (the reference's batch is a Python loop over channels, tests/stft_ssq_test.py:230), so the
+ * data path has no collective; a consumer that wants every rank to hold all shards calls ssq_gather_shards after its
+ * plan exec.  RCCL (librccl.so) is dlopen'd on first use -- no link-time dependency, a clear error when absent.
+ * One process per GPU: rank 0 makes the 128-byte id (ssq_rccl_unique_id) and hands it to the others out of band
+ * (MPI, a file, torch.distributed, ...); every rank then calls ssq_rccl_comm_init on its own device.  `comm` may also
+ * be a ncclComm_t the caller created itself. */
+int ssq_rccl_available(void);                                 /* 1 if librccl.so loads */
+int ssq_rccl_unique_id(void* id128);                          /* ncclGetUniqueId */
+int ssq_rccl_comm_init(void** comm, int n_ranks, const void* id128, int rank);   /* ncclCommInitRank (collective) */
+int ssq_rccl_comm_info(void* comm, int* n_ranks, int* rank);  /* ncclCommCount / ncclCommUserRank */
+int ssq_rccl_comm_destroy(void* comm);
+/* ncclAllGather of `bytes_per_rank` bytes: d_recv[rank][bytes_per_rank], rank order = batch order; async on `stream` */
+int ssq_gather_shards(void* comm, const void* d_send, void* d_recv, int64_t bytes_per_rank, void* stream);
+
 /* ---- host-path caches ---------------------------------------------------------
  * The *_host entry points keep plans (keyed by their configuration), device scratch and two streams between
  * calls, and pipeline H2D / kernels / D2H over the signals of a batch.  Results that live in blocks of the

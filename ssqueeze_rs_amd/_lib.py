@@ -91,6 +91,12 @@ _SIGNATURES = {
     "ssq_cwt_plan_exec_cwt": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, vp, vp, vp, i64, vp]),
     "ssq_cwt_plan_exec_ssq": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                         vp, vp, vp, vp, vp, i64, vp]),
+    "ssq_rccl_available": (C.c_int, []),
+    "ssq_rccl_unique_id": (C.c_int, [vp]),
+    "ssq_rccl_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.c_int]),
+    "ssq_rccl_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ssq_rccl_comm_destroy": (C.c_int, [vp]),
+    "ssq_gather_shards": (C.c_int, [vp, vp, vp, i64, vp]),
     "ssq_pinned_alloc": (C.c_int, [C.POINTER(vp), i64]),
     "ssq_pinned_free": (C.c_int, [vp]),
     "ssq_host_cache_limit": (C.c_int, [i64]),

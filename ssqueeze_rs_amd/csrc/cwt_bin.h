@@ -12,11 +12,10 @@ namespace ssq {
 // ------------------------------------------------ phase transform + reassignment ----
 // ssq_cwt.rs:15-47 (phase_cwt) and :116-222 (ssqueeze).
 // Phase transform and bin of one (scale, time) element: returns the Tx row (after flipud) or -1.
+// The upstream variant's rule (old/ssqueezepy/algos.py:899-940), plain arithmetic in T: the normalised wavelets cannot
+// overflow fp32.  Called by the column-ordered reassignment only (cwt_reassign_kernel), never by the tile kernels.
 template <typename T>
-__device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cpx<T> dW, T& w) {
-  const T two_pi = (T)(2.0 * 3.14159265358979323846);
-  if (p.variant) {
-    // upstream (old/ssqueezepy/algos.py:899-940), plain arithmetic in T: the normalised wavelets cannot overflow fp32
+__device__ __forceinline__ int reassign_bin_upstream(const CwtSsqDev<T>& p, cpx<T> Wv, cpx<T> dW, T& w) {
     const T A = dW.x, B = dW.y, C = Wv.x, D = Wv.y;
     if (!(hypot(C, D) > p.gamma)) {
       w = (T)INFINITY;
@@ -28,6 +27,10 @@ __device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cp
     if (!(v == v)) bin = 0;
     return p.flipud ? (p.na - 1 - bin) : bin;
   }
+
+template <typename T>
+__device__ __forceinline__ int reassign_bin(const CwtSsqDev<T>& p, cpx<T> Wv, cpx<T> dW, T& w) {
+  const T two_pi = (T)(2.0 * 3.14159265358979323846);
   bool small;
   if constexpr (sizeof(T) == 4) {
     // pre-scaled ratio: the reference's GMW is un-normalised (peak ~4e17), so |Wx|^2 and

@@ -799,7 +799,7 @@ __global__ void cwt_reassign_kernel(CwtSsqDev<T> p) {
       const long long o = (long long)i * p.N + j;
       const cpx<T> Wv = Wb[u];
       T w;
-      const int kk = reassign_bin(p, Wv, dWb[u], w);
+      const int kk = p.variant ? reassign_bin_upstream(p, Wv, dWb[u], w) : reassign_bin(p, Wv, dWb[u], w);
       if (p.wk) p.wk[o] = {w, (T)kk};
       // consecutive scales that land in the same row are summed in registers and written once (near a ridge many do)
       if (kk != k_cur) {

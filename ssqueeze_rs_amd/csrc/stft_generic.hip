@@ -114,7 +114,7 @@ __global__ void reassign_cols_kernel(StftDev<T> p, const cpx<T>* __restrict__ Sx
     const cpx<T> S = Sx[o], dS = dSx[o];
     T w;
     int kk;
-    const bool keep = phase_bin<T>(p, i, S, dS, w, kk);
+    const bool keep = (p.variant & 1) ? phase_bin_upstream<T>(p, i, S, dS, w, kk) : phase_bin<T>(p, i, S, dS, w, kk);
     if (p.out_kind == 3) {
       p.out[o] = {w, keep ? (T)kk : (T)-1};
     } else if (keep) {

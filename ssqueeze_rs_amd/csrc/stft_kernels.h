@@ -101,9 +101,11 @@ hipError_t launch_reassign_cols(const StftDev<T>& p, const cpx<T>* Sx, const cpx
 // Returns false when the bin is skipped (|Sx| < gamma or w infinite, :23,:278).
 // `dS` is dSx times the factor folded into p.two_pi_eff (alpha in the fused kernel, 1 otherwise).
 // ---------------------------------------------------------------------------
+// The upstream variant's rule (unfused kernels only; kept OUT of phase_bin: the fused kernels inline that nine times per
+// frame and the extra branch cost the fp64 kernel 30 % through register pressure).
 template <typename T>
-__device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
-  if (p.variant & 1) {
+__device__ __forceinline__ bool phase_bin_upstream(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
+  {
     // upstream (old/ssqueezepy/algos.py:957-968), evaluated in T like numba does for the array's dtype
     const T A = dS.x, B = dS.y, C = S.x, D = S.y;
     const T w = fabs(p.ssq_freqs[i] - (B * C - A * D) / ((C * C + D * D) * (T)6.283185307179586));
@@ -117,6 +119,10 @@ __device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, 
     kk_out = kk;
     return keep;
   }
+}
+
+template <typename T>
+__device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, cpx<T> dS, T& w_out, int& kk_out) {
   const T den = S.x * S.x + S.y * S.y;
   const T num = dS.y * S.x - dS.x * S.y;
   const T two_pi = p.two_pi_eff;                    // 6.283185307179586 (ssq_stft.rs:32) [* alpha]

@@ -63,3 +63,21 @@ def test_world2_gloo_through_the_self_launcher(argv, signals, last_first, scalin
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["signals"] == signals and d["last_first"] == last_first
     assert d["scaling"] == scaling and abs(d["wall"] - 0.5) < 1e-12
+
+
+def test_world8_strong_c3_shape_end_to_end_over_gloo():
+    """BASELINE config 3 as the driver launches it at N = 8: `--gpus 8 --total-batch 256` -> 8 ranks (gloo on CPU, the
+    stub step of tests/helpers/rank_echo.py), 32 signals each, contiguous blocks, MAX-over-ranks timing, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    argv = ["--gpus", "8", "--total-batch", "256"]
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.spawn_ranks(8, %r, script=%r))" % (ROOT, argv, HELPER))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["signals"] == 256 and d["total"] == 256 and d["scaling"] == "strong"
+    assert d["last_first"] == 224                       # rank 7 starts at signal 7 * 32
+    assert abs(d["wall"] - 2.0) < 1e-12                 # MAX over ranks of 0.25 * (rank + 1)
