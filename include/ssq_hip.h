@@ -52,6 +52,8 @@ enum {
 /* ---- library / device ----------------------------------------------------- */
 const char* ssq_last_error(void);
 const char* ssq_hello_from_bin(void);                    /* lib.rs:16-19 */
+/* 1 in -DSSQ_TUNING variant builds (tuning / ablation environment switches compiled in), 0 in the product library */
+int ssq_build_has_tuning(void);
 int ssq_device_count(int* count);
 int ssq_set_device(int device);
 int ssq_device_info(int* cu_count, int64_t* hbm_bytes, char* name, int name_len);

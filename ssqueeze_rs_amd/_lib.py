@@ -36,6 +36,7 @@ dp = C.POINTER(C.c_double)
 _SIGNATURES = {
     "ssq_last_error": (C.c_char_p, []),
     "ssq_hello_from_bin": (C.c_char_p, []),
+    "ssq_build_has_tuning": (C.c_int, []),
     "ssq_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ssq_set_device": (C.c_int, [C.c_int]),
     "ssq_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(i64), C.c_char_p, C.c_int]),

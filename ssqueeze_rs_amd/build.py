@@ -73,9 +73,11 @@ def build_lib(force: bool = False, verbose: bool = True, extra_flags=(), suffix:
 
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
-        print(build_lib(extra_flags=("-DSSQ_STAMPS", "-DSSQ_ABLATE_HOOKS"), suffix="diag"))
+        print(build_lib(extra_flags=("-DSSQ_STAMPS", "-DSSQ_ABLATE_HOOKS", "-DSSQ_TUNING"), suffix="diag"))
     elif "--abl" in sys.argv:       # timing experiments: SSQ_ABLATE=<mask> skips stages (results wrong)
-        print(build_lib(extra_flags=("-DSSQ_ABLATE_HOOKS",), suffix="abl"))
+        print(build_lib(extra_flags=("-DSSQ_ABLATE_HOOKS", "-DSSQ_TUNING"), suffix="abl"))
+    elif "--tune" in sys.argv:      # the measured-slower alternatives behind their environment switches (SSQ_CWT_FUSED, ...)
+        print(build_lib(extra_flags=("-DSSQ_TUNING",), suffix="tune"))
     elif "--variant" in sys.argv:   # python -m ssqueeze_rs_amd.build --variant NAME -DFOO=1 ...  -> libssq_hip_NAME.so
         name = sys.argv[sys.argv.index("--variant") + 1]
         idx = sys.argv.index("--variant") + 2          # everything after the name goes to hipcc (-D..., -mllvm ...)

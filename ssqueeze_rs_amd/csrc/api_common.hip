@@ -1,5 +1,6 @@
 // api_common.hip -- library/device plumbing and the host-math entry points of the C-ABI
 // (include/ssq_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -11,6 +12,14 @@
 namespace ssq {
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+const char* tune_env(const char* name) {
+#ifdef SSQ_TUNING
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 }  // namespace ssq
 
 using namespace ssq;
@@ -184,3 +193,11 @@ int ssq_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 
 }  // extern "C"
+
+extern "C" int ssq_build_has_tuning(void) {
+#ifdef SSQ_TUNING
+  return 1;
+#else
+  return 0;
+#endif
+}

@@ -86,7 +86,7 @@ struct ssq_cwt_plan {
   // the tile kernel's phases add, so the extra store-phase arithmetic costs more than the bytes it saves.  Default off.
   bool fused_ssq() const {
     if (!can_fuse_ssq()) return false;
-    const char* e = std::getenv("SSQ_CWT_FUSED");
+    const char* e = tune_env("SSQ_CWT_FUSED");
     return e && std::atoi(e) != 0;
   }
 };
@@ -98,7 +98,7 @@ constexpr long long kZoomTabQ = 4096;   // twiddle table extent of the single-pa
 // longest single-pass (mode Z) transform actually used (SSQ_CWT_ZMAXQ, a power of two <= 4096; read at plan creation)
 long long zoom_max_q() {
   long long q = 2048;
-  if (const char* e = std::getenv("SSQ_CWT_ZMAXQ")) {
+  if (const char* e = tune_env("SSQ_CWT_ZMAXQ")) {
     const long long v = std::atoll(e);
     if (v >= 16 && v <= kZoomTabQ && (v & (v - 1)) == 0) q = v;
   }
@@ -108,7 +108,7 @@ long long zoom_max_q() {
 // SSQ_CWT_GROUP (read per call): n > 0 reassigns every n scales right behind their transforms (while their Wx / dWx are
 // still in the Infinity Cache) instead of once per call; default 0: measured 5 % slower on C4, profiles/r02_ab_cwt_group.txt
 int ssq_group_env(int dflt) {
-  const char* e = std::getenv("SSQ_CWT_GROUP");
+  const char* e = tune_env("SSQ_CWT_GROUP");
   if (!e) return dflt;
   const int v = std::atoi(e);
   return v < 0 ? dflt : v;
@@ -713,7 +713,7 @@ int exec_ssq_typed(ssq_cwt_plan* pl, const void* d_x, long long batch, int freq_
   // of a cleared Tx; 1 (default) = bitmap, Tx cleared beside the transforms; 2 = bitmap and the kernel writes the
   // untouched rows as zeros itself, no clear (measured slower on C4: the clear overlaps the transforms, the zero rows
   // would not -- profiles/r02_ab_cwt_sweep.txt)
-  const char* sweep_env = std::getenv("SSQ_CWT_SWEEP");
+  const char* sweep_env = tune_env("SSQ_CWT_SWEEP");
   const int sweep_mode = sweep_env ? std::atoi(sweep_env) : 1;
   const bool os = sizeof(T) == 4 && group == 0 && (pl->os_s1 > pl->os_s0 || pl->os_z1 > pl->os_z0);   // time-tile family
   const bool sweep = !ups && !os && group == 0 && cwt_reassign_can_sweep<T>(n) && sweep_mode != 0;
@@ -926,7 +926,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   } else {
     pl->two_step = true;
     pl->log_p2 = lp / 2;                                          // step B gets the shorter transforms (two blocks per CU)
-    if (const char* e = std::getenv("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 0)
+    if (const char* e = tune_env("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 0)
     pl->log_p1 = lp - pl->log_p2;
   }
   // SSQ_CWT_REG=0 keeps the tile kernels for the two-step scales (A/B and tests)
@@ -937,7 +937,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   }
   const long long csz = dtype == SSQ_F32 ? 8 : 16;
   long long chunk_mb = 128;                                      // ybuf of a chunk stays inside the 256 MB Infinity Cache
-  if (const char* e = std::getenv("SSQ_CWT_CHUNK_MB")) chunk_mb = std::atoll(e) > 0 ? std::atoll(e) : chunk_mb;   // tuning switch
+  if (const char* e = tune_env("SSQ_CWT_CHUNK_MB")) chunk_mb = std::atoll(e) > 0 ? std::atoll(e) : chunk_mb;   // tuning switch
   long long ch = (chunk_mb << 20) / (2 * pl->P * csz);
   if (ch < 1) ch = 1;
   if (ch > (na > 0 ? na : 1)) ch = (na > 0 ? na : 1);
@@ -946,6 +946,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   pl->band.assign((size_t)na, (int)(pl->P / 2 + 1));
   // SSQ_CWT_NOPRUNE=1 (tests): every scale through the plain two-step transform, no band-limit shortcuts
   const char* noprune = std::getenv("SSQ_CWT_NOPRUNE");
+  const char* os_env = std::getenv("SSQ_CWT_OS");               // tests: 0 switches the time-tile family off
   if ((pl->two_step || pl->big) && !(noprune && noprune[0] == '1')) {
     const double h = 2.0 * M_PI / (double)pl->P;                     // base.rs:20
     const double wmax = ups ? upstream_support(wavelet, p0, p1, dtype) : wavelet_support(wavelet, dtype);
@@ -964,7 +965,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   // sigma_t = a for the Morlet wavelet, 4.943 a for the GMW: 1 / the spectral width at the peak) and is negligible at the
   // Nyquist frequency (so that the spectrum's cut leaves no slow tail); SSQ_CWT_OS=0 switches it off
   {
-    const char* e = std::getenv("SSQ_CWT_OS");
+    const char* e = os_env;
     if (!ups && dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0)) {
       const double sig = wavelet == SSQ_WAVELET_MORLET ? 1.0 : 4.943;
       const double a_hi = (double)kOsHalo / (6.0 * sig);
@@ -988,7 +989,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
         pl->os_s0 = best0;
         pl->os_s1 = best1;
         // the scales whose wavelet fits HALF the halo take the 4096-point tiles (SSQ_CWT_OS_ROWS=8: all on 8192 points)
-        const char* er = std::getenv("SSQ_CWT_OS_ROWS");
+        const char* er = tune_env("SSQ_CWT_OS_ROWS");
         int mid = best0;
         if (!(er && std::atoi(er) == 8))
           while (mid < best1 && scales[mid] <= 0.5 * a_hi) ++mid;
@@ -997,7 +998,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
         pl->os_d1 = best1;
         // behind them the long wavelets that are band-limited below 1 / 64 cycles per sample: 16-fold decimated tiles
         // (halo 16 * 2048 samples; psih_s[k] == 0 from band[s] <= P / 32 on); SSQ_CWT_OS_DEC=0 keeps the transforms
-        const char* ed = std::getenv("SSQ_CWT_OS_DEC");
+        const char* ed = tune_env("SSQ_CWT_OS_DEC");
         if (!(ed && std::atoi(ed) == 0)) {
           int d1 = best1;
           while (d1 < (int)na && scales[d1] <= a_hi * (double)(1 << kOsLogDec) && pl->zoom_logq[(size_t)d1] == 0 &&
@@ -1008,7 +1009,7 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
         // in front of them the finest scales, whose psih is NOT negligible at Nyquist, on tiles of the analytic signal
         // (register-core plans compute it with one extra transform); the continued spectrum must vanish by 2 pi:
         // Morlet a >= 1.97, GMW a >= 0.64.  SSQ_CWT_OS_ANALYTIC=0 keeps the register-core transforms for them
-        const char* ea = std::getenv("SSQ_CWT_OS_ANALYTIC");
+        const char* ea = tune_env("SSQ_CWT_OS_ANALYTIC");
         pl->os_a0 = best0;
         if (pl->reg && !(ea && std::atoi(ea) == 0)) {
           const double a_ext = wavelet == SSQ_WAVELET_MORLET ? 1.97 : 0.64;
@@ -1022,8 +1023,8 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   // full-circle phase blocks for the band-limited scales: 2 N <= P (the kept samples lie inside the middle half of the
   // padded length, which is what the tile kernel emits), spectrum below 2048 bins; SSQ_CWT_OS_FULL=0 keeps mode Z + the column reassignment for them
   {
-    const char* e = std::getenv("SSQ_CWT_OS");
-    const char* ef = std::getenv("SSQ_CWT_OS_FULL");
+    const char* e = os_env;
+    const char* ef = tune_env("SSQ_CWT_OS_FULL");
     if (!ups && dtype == SSQ_F32 && pl->two_step && !(e && std::atoi(e) == 0) && !(ef && std::atoi(ef) == 0) &&
         2 * pl->N <= pl->P && n_signal >= 64LL * kOsL) {
       bool ascending = true;
@@ -1128,10 +1129,11 @@ int ssq_cwt_plan_exec_ssq(ssq_cwt_plan* pl, const void* d_x, int64_t batch, int 
 // ---- D2H of signal b on a second stream while signal b+1 computes -----------------------------------------------
 namespace {
 
-// the switches plan creation reads from the environment are part of the key (tests flip them between calls)
+// the four TEST hooks plan creation reads from the environment are part of the key (tests flip them between calls);
+// tuning switches exist only in -DSSQ_TUNING builds (ssq_common.h::tune_env) and are not
 std::string plan_env() {
   std::string k;
-  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_P2UP", "SSQ_CWT_CHUNK_MB", "SSQ_CWT_ZMAXQ", "SSQ_CWT_REG", "SSQ_CWT_OS", "SSQ_CWT_OS_ROWS", "SSQ_CWT_OS_DEC", "SSQ_CWT_OS_FULL", "SSQ_CWT_OS_ANALYTIC"}) {
+  for (const char* v : {"SSQ_CWT_NOPRUNE", "SSQ_CWT_FORCE_BIG", "SSQ_CWT_REG", "SSQ_CWT_OS"}) {
     const char* e = std::getenv(v);
     k += e ? e : "";
     k += '|';

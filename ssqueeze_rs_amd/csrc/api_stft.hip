@@ -169,9 +169,9 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
     p.keep_bias = bias;
   }
   {
-    const char* ab = std::getenv("SSQ_ABLATE");
+    const char* ab = tune_env("SSQ_ABLATE");            // variant builds only
     p.ablate = ab ? std::atoi(ab) : 0;
-    const char* st = std::getenv("SSQ_STAMPS_PTR");   // diagnostic builds: device buffer address
+    const char* st = tune_env("SSQ_STAMPS_PTR");   // diagnostic builds: device buffer address
     p.stamps = st ? (unsigned long long*)std::strtoull(st, nullptr, 0) : nullptr;
   }
   return p;

@@ -8,6 +8,10 @@ namespace ssq {
 
 // ---------------------------------------------------------------- errors ----
 void set_error(const std::string& msg);
+// Tuning / diagnostic switches (measured-slower alternatives, ablation masks, stamp buffers) exist only in variant
+// builds (-DSSQ_TUNING: `python -m ssqueeze_rs_amd.build --variant tune -DSSQ_TUNING`, and the --abl / --stamps builds):
+// there this is getenv, in the product library it returns NULL -- the shipped dispatch reads no tuning environment.
+const char* tune_env(const char* name);
 #define SSQ_FAIL(msg)                 \
   do {                                \
     ::ssq::set_error(msg);            \

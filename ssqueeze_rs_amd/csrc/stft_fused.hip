@@ -1295,7 +1295,7 @@ static hipError_t launch_one(const StftDev<T>& p0, int cu_count, long long batch
   int hiocc = 0;
   if constexpr (sizeof(T) == 4 && LOGN == 10) {
     static const int mode = []() {
-      const char* e = std::getenv("SSQ_HIOCC");
+      const char* e = tune_env("SSQ_HIOCC");              // variant builds only (both alternatives measured slower)
       return e ? std::atoi(e) : SSQ_HIOCC_DEFAULT;
     }();
     if ((p0.out_kind == 0 || p0.out_kind == 3) && p0.n_eff == C::N) hiocc = mode;   // SSQ_OUT_WK: the (w, k) hook of the kernel that serves Tx

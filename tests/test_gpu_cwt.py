@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import ssq_oracle as o
-from ssqueeze_rs_amd import _rs
+from ssqueeze_rs_amd import _lib, _rs
 
 pytestmark = pytest.mark.gpu
 
@@ -270,6 +270,8 @@ def test_fused_step_b_equals_unfused(monkeypatch):
         x = _sig(20000, 11, dtype)
         outs = []
         for mode in ("0", "1"):
+            if not _lib.load().ssq_build_has_tuning():
+                pytest.skip("SSQ_CWT_FUSED exists only in -DSSQ_TUNING builds (python -m ssqueeze_rs_amd.build --tune)")
             monkeypatch.setenv("SSQ_CWT_FUSED", mode)
             outs.append(_rs.ssq_cwt(x, wavelet="morlet", nv=6, _debug=True))
         (T0, f0, d0), (T1, f1, d1) = outs
@@ -344,6 +346,8 @@ def test_ssq_cwt_sweep_reassignment_equals_clear_and_rmw(dtype, monkeypatch):
     assert np.isfinite(Tx.view(dtype)).all()
     assert np.count_nonzero(Tx) > 0
     for mode in ("0", "2"):                               # read-modify-write of a cleared Tx | bitmap + own zero rows
+        if not _lib.load().ssq_build_has_tuning():
+            continue                              # the alternatives exist only in -DSSQ_TUNING builds
         monkeypatch.setenv("SSQ_CWT_SWEEP", mode)
         Tx0, f0 = _rs.ssq_cwt(x, wavelet="morlet", scales=scales)
         assert np.array_equal(f, f0) and np.array_equal(Tx, Tx0), mode
