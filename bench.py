@@ -164,7 +164,8 @@ def cpu_baseline(N, n_fft, hop, budget_s=20.0):
     return {
         "value": v, "unit": "TF-bins/s", "cores": cores, "kind": "port",
         "sample": f"{done} signal(s) x 2^{int(np.log2(N))} samples, fp64, reference-faithful structure "
-                  f"(2 FFTs/frame over {cores} OpenMP threads, serial phase, serial linear-scan reassignment), "
+                  f"(2 scalar radix-2 FFTs/frame, C built -march=x86-64-v2, over {cores} OpenMP threads; serial phase, "
+                  f"serial linear-scan reassignment), "
                   f"{tt:.1f} s",
         "optimized_value": out["optimized"][0],
         "optimized_sample": f"{out['optimized'][1]} signal(s), arithmetic binning + column-parallel reassignment, "
@@ -208,7 +209,11 @@ class Leg:
                                                     row.ctypes.data_as(C.c_void_p), self.N * self.esz, self.stream))
         self._lib.check(self.lib.ssq_stream_sync(self.stream))
 
+    n_step_calls = 0          # launches of the batch pass so far (= dispatches of the interior-tile kernel)
+    timed_first = None        # index of the first TIMED one: tools/trace_timed.py cuts a rocprofv3 kernel trace there
+
     def step(self):
+        self.n_step_calls += 1
         self._lib.check(self.lib.ssq_stft_plan_exec(self.plan, self._lib.OUT_TX, self.d_x, self.B, self.d_out,
                                                     None, 0, self.stream))
 
@@ -232,6 +237,7 @@ class Leg:
             evs.append((a, b_))
         if before:
             before()
+        self.timed_first = self.n_step_calls
         t0 = time.perf_counter()
         for a, b_ in evs:
             _lib.check(lib.ssq_event_record(a, self.stream))
@@ -260,10 +266,10 @@ class Leg:
         self._lib.check(self.lib.ssq_stream_sync(self.stream))
         return out
 
-    def single(self, b):
+    def single(self, b, kind=None):
         """Signal b through the single-signal path (batch = 1: one launch of the edge-capable kernel)."""
         cd = np.complex64 if self.f32 else np.complex128
-        self._lib.check(self.lib.ssq_stft_plan_exec(self.plan, self._lib.OUT_TX,
+        self._lib.check(self.lib.ssq_stft_plan_exec(self.plan, self._lib.OUT_TX if kind is None else kind,
                                                     C.c_void_p(self.d_x.value + b * self.N * self.esz), 1,
                                                     self.d_one, None, 0, self.stream))
         out = np.empty((self.n_freqs, self.n_frames), dtype=cd)
@@ -287,16 +293,35 @@ class Leg:
                 rep["bitwise_equal_single_signal_path"] = False
         ok = rep["bitwise_equal_single_signal_path"] and bool(np.isfinite(t0.view(t0.real.dtype)).all())
         gpath = os.path.join(ROOT, "tests", "golden", "c2_summary.npz")
+        rep["golden_checked"] = False            # true only when signal 0 IS the C2 signal and the fixtures are present
         if first_seed == 0 and (self.N, self.n_fft, self.hop) == (1 << 20, 1024, 256) and os.path.exists(gpath):
             g = np.load(gpath)
             dw = 0.5 / (self.n_freqs - 1)
             scale = float(g["sx_absmax"]) * dw
             e_col = float(np.abs(t0.astype(np.complex128).sum(0) - g["col_sums"]).max() / scale)
             e_row = float(np.abs(np.abs(t0).sum(1) - g["row_energy"]).max() / g["row_energy"].max())
-            rep["c2_colsum_relerr"] = e_col       # column sums are invariant under bin flips
-            rep["c2_row_energy_relerr"] = e_row
-            tol_col = 1e-4 if self.f32 else 1e-9
-            ok = ok and e_col <= tol_col and e_row <= 2e-2
+            rep["c2_colsum_relerr"] = e_col       # column sums are invariant under bin flips (measured 8.6e-7 fp32)
+            rep["c2_row_energy_relerr"] = e_row   # measured 4.1e-5 fp32: the bound is ~10x that, not a loose 2e-2
+            tol_col = 1e-5 if self.f32 else 1e-9
+            tol_row = 5e-4 if self.f32 else 1e-8
+            ok = ok and e_col <= tol_col and e_row <= tol_row
+            rep["golden_checked"] = True
+            kpath = os.path.join(ROOT, "tests", "golden", "c2_k_cols.npz")
+            if os.path.exists(kpath):
+                # end-to-end bin parity: the Tx kernel's OWN bins (SSQ_OUT_WK hook of the timed kernel) against the
+                # fp64 oracle's on 256 frames -- the measured mismatch rate SURVEY 8(c) asks to report
+                gk = np.load(kpath)
+                wk = self.single(0, kind=self._lib.OUT_WK)
+                k_own = np.rint(wk.imag[:, gk["col_index"]]).astype(np.int64)
+                k_or = gk["k"].astype(np.int64)
+                shp = tuple(int(v) for v in gk["shape"])
+                strong = np.unpackbits(gk["strong"])[: shp[0] * shp[1]].reshape(shp).astype(bool)
+                both = strong & (k_own >= 0) & (k_or >= 0)
+                rate = float((k_own[both] != k_or[both]).mean())
+                rep["bin_mismatch_rate_vs_fp64_oracle"] = rate          # measured 1.3e-5 (profiles/r03_bin_parity.json)
+                rep["bin_mismatch_max_abs_dk"] = int(np.abs(k_own[both] - k_or[both]).max())
+                rep["bins_compared"] = int(both.sum())
+                ok = ok and rate <= (5e-5 if self.f32 else 1e-6) and rep["bin_mismatch_max_abs_dk"] <= 1
         rep["ok"] = bool(ok)
         return rep
 
@@ -319,11 +344,14 @@ def roofline_of(leg, kern_ms, traffic, kernel_name):
             "traffic": traffic,
             "traffic_source": TRAFFIC_FILE if traffic is not None else None,
             "kernel": kernel_name, "kernel_ms_avg": k_avg, "kernel_ms_min": float(np.min(kern_ms)),
+            # which dispatches of the interior-tile kernel were the timed ones (0-based, in launch order): a kernel trace
+            # of this command restricted to them is what `kernel_ms_avg` must agree with (tools/trace_timed.py)
+            "timed_dispatches": None if leg.timed_first is None else [leg.timed_first, leg.timed_first + len(kern_ms)],
             "kernel_ms_all": [round(float(v), 4) for v in kern_ms],
             "alg_bytes_per_launch": alg}
 
 
-def cwt_c4_leg(lib, _lib, steps=5):
+def cwt_c4_leg(lib, _lib, steps=5, cpu=True):
     """BASELINE config 4 through the plan API (tools/bench_cwt.py is the full tool): ms per call, bins/s and the
     algorithmic-bytes fraction of the HBM roof; traffic from the committed PMC passes if present."""
     import ctypes as C
@@ -346,6 +374,26 @@ def cwt_c4_leg(lib, _lib, steps=5):
             _lib.check(lib.ssq_device_sync())
 
         run()
+        # what is timed is checked: the result against the committed oracle summary of C4 (tests/golden/c4_summary.npz,
+        # the quantities tests/test_gpu_cwt_full.py checks: block sums of the column sums -- invariant under bin flips --,
+        # row energies, the norm)
+        check = {"validated": None}
+        gpath = os.path.join(ROOT, "tests", "golden", "c4_summary.npz")
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            Tx = np.empty((na, N), dtype=np.complex64)
+            _lib.check(lib.ssq_memcpy_d2h(Tx.ctypes.data_as(C.c_void_p), dT, Tx.nbytes, None))
+            _lib.check(lib.ssq_device_sync())
+            nb = g["block_col_sums"].shape[0]
+            blk = Tx.sum(0, dtype=np.complex128).reshape(nb, N // nb).sum(1)
+            e_blk = float(np.abs(blk - g["block_col_sums"]).max() / np.abs(g["block_col_sums"]).max())
+            e_row = float(np.abs(np.abs(Tx).sum(1, dtype=np.float64) - g["row_energy"]).max() / g["row_energy"].max())
+            nrm = float(np.sqrt((Tx.real.astype(np.float64) ** 2 + Tx.imag.astype(np.float64) ** 2).sum()))
+            e_nrm = abs(nrm - float(g["norm2"])) / float(g["norm2"])
+            check = {"validated": bool(e_blk <= 2e-4 and e_row <= 1e-3 and e_nrm <= 1e-4),
+                     "validation": {"block_colsum_relerr": e_blk, "row_energy_relerr": e_row, "norm_relerr": e_nrm,
+                                    "golden": "tests/golden/c4_summary.npz"}}
+            del Tx
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
@@ -356,14 +404,33 @@ def cwt_c4_leg(lib, _lib, steps=5):
                 lib.ssq_dev_free(ptr)
         lib.ssq_cwt_plan_destroy(plan)
     alg = 4 * N + 8 * na * N
-    out = {"workload": "ssq_cwt morlet, 256 log scales, 1 x 2^20, fp32", "ms_per_call": dt * 1e3,
+    out = {"workload": "ssq_cwt morlet, 256 log scales, 1 x 2^20, fp32", "ms_per_call": dt * 1e3, **check,
            "value": na * N / dt, "unit": "TF-bins/s", "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
            "workspace_GB": wsb / 1e9}
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_cwt_traffic.json")
-    if os.path.exists(tf):
-        with open(tf) as fh:
-            out["traffic_over_algorithmic"] = json.load(fh)["total_GB_per_call"] * 1e9 / alg
+    for name in ("r03_cwt_traffic.json", "r02_cwt_traffic.json"):
+        tf = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                out["traffic_over_algorithmic"] = json.load(fh)["total_GB_per_call"] * 1e9 / alg
+            out["traffic_source"] = "profiles/" + name
+            break
+    if cpu:
+        out["cpu_baseline"] = cwt_cpu_baseline(N, scales)
     return out
+
+
+def cwt_cpu_baseline(N, scales):
+    """The oracle's C restatement of ssq_cwt.rs (oracle/ssq_ref.c::ssq_ref_ssq_cwt: forward FFT, per scale two inverse
+    FFTs over OpenMP threads, phase transform, column-parallel reassignment), timed on this box's host cores on C4."""
+    from oracle import ref_c                         # the timed CPU baseline (kind "port")
+    from ssqueeze_rs_amd.synth import synth_signal
+    x = synth_signal(N, 0, np.float64)
+    t0 = time.perf_counter()
+    ref_c.ssq_cwt(x, scales, wavelet="morlet")
+    t = time.perf_counter() - t0
+    return {"value": len(scales) * N / t, "unit": "TF-bins/s", "cores": ref_c.num_threads(), "kind": "port",
+            "sample": f"the whole C4 call once (1 x 2^20, 256 scales, fp64; radix-2 C FFTs built -march=x86-64-v2, "
+                      f"OpenMP over scales / columns), {t:.1f} s"}
 
 
 def main():
@@ -428,9 +495,16 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             validation["ok_all_ranks"] = bool(okt.item())
 
-    # Secondary legs (N = 1 only) run BEFORE the headline leg: they are part of this bench's output anyway, and the
-    # device is then at its sustained clocks when the W warm-up steps start (an idle MI355X needs ~30 ms of load to
-    # get there: the first steps after an idle gap run ~15 % slower, see roofline.kernel_ms_all).
+    wall, kern_ms = leg.timed(args.steps, args.warmup, before=fence, after=torch.cuda.synchronize,
+                              settle_ms=args.settle_ms)
+    if use_dist:
+        dist.barrier()
+        tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    # Secondary legs (N = 1 only) run AFTER the headline's timed region (round 2 ran them before it, which lengthened the
+    # undisclosed warm-up): the only load in front of the K timed steps is the disclosed run-in (settle_ms) + W steps.
     sec = None
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}
@@ -456,17 +530,9 @@ def main():
         l64.close()
         # (3) BASELINE config 4: ssq_cwt, 1 x 2^20, 256 log scales, Morlet, fp32 (wall clock around synchronised calls)
         try:
-            sec["c4_ssq_cwt_f32"] = cwt_c4_leg(lib, _lib)
+            sec["c4_ssq_cwt_f32"] = cwt_c4_leg(lib, _lib, cpu=not args.no_cpu_baseline)
         except Exception as e:                                    # a secondary leg must not take the headline down
             sec["c4_ssq_cwt_f32"] = {"error": str(e)}
-
-    wall, kern_ms = leg.timed(args.steps, args.warmup, before=fence, after=torch.cuda.synchronize,
-                              settle_ms=args.settle_ms)
-    if use_dist:
-        dist.barrier()
-        tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
 
     gather = None
     if args.gather and use_dist:

@@ -20,6 +20,9 @@ def load():
         lib.ssq_ref_ssq_stft.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_double,
                                          C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ssq_ref_ssq_cwt.restype = C.c_int
+        lib.ssq_ref_ssq_cwt.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_double, C.c_int,
+                                        C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         lib.ssq_ref_num_threads.restype = C.c_int
         _lib = lib
     return _lib
@@ -49,3 +52,19 @@ def ssq_stft(x, window_sized, n_fft, hop, fs=1.0, padtype="reflect", squeezing="
     if rc != 0:
         raise RuntimeError("ssq_ref_ssq_stft failed")
     return (Tx, f, k) if want_k else (Tx, f)
+
+
+def ssq_cwt(x, scales, wavelet="morlet", dt=1.0, flipud=True, gamma=None, nthreads=0):
+    """oracle/ssq_ref.c::ssq_ref_ssq_cwt (ssq_cwt.rs structure: maprange "peak", log ssq_freqs, reflect, "sum")."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.ascontiguousarray(scales, dtype=np.float64)
+    n, na = x.shape[0], s.shape[0]
+    Tx = np.empty((na, n), dtype=np.complex128)
+    f = np.empty(na, dtype=np.float64)
+    rc = lib.ssq_ref_ssq_cwt(x.ctypes.data, n, s.ctypes.data, na, 1 if wavelet == "morlet" else 0, float(dt),
+                             int(bool(flipud)), -1.0 if gamma is None else float(gamma), int(nthreads),
+                             Tx.ctypes.data, f.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("ssq_ref_ssq_cwt failed (%d)" % rc)
+    return Tx, f

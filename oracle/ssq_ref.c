@@ -245,3 +245,102 @@ int ssq_ref_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ssq_cwt, the same way: the structure of rust/src/spectral/ssq_cwt.rs (bench.py's cpu_baseline of the C4 leg)
+ *   :339-350  forward FFT of the padded signal (utils/array.rs:9-11, :52-98)        serial
+ *   :365-423  per scale: wavelet (cwt.rs:492-547), TWO inverse FFTs of length P       parallel over scales
+ *   :434-435  unpad                                                                   (inside the loop here)
+ *   :15-47    phase_cwt                                                               parallel over rows
+ *   :116-222  ssqueeze: bin formula, drop out-of-range, flipud, Tx += Wx              parallel over columns
+ * wavelet: 1 = morlet (mu = 6), else the un-normalised GMW.  Tx: interleaved complex [na][n]; ssq_freqs: [na].
+ * Memory: Wx, dWx, Tx of na * n complex doubles each (C4: 3 x 4.3 GB).
+ */
+static long next_pow2_ceil(long n) {
+  long p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+int ssq_ref_ssq_cwt(const double* x, long n, const double* scales, long na, int wavelet, double dt, int flipud,
+                    double gamma, int nthreads, double* Tx, double* ssq_freqs) {
+  if (n < 1 || na < 2) return 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  const long P = next_pow2_ceil(n + n / 2);                       /* utils/array.rs:9-11 with cwt.rs:87 */
+  const long n1 = (P - n) / 2;
+  cd* xh = (cd*)calloc((size_t)P, sizeof(cd));
+  cd* twf = (cd*)malloc((size_t)P * sizeof(cd));
+  cd* twi = (cd*)malloc((size_t)P * sizeof(cd));
+  cd* Wx = (cd*)malloc((size_t)na * n * sizeof(cd));
+  cd* dWx = (cd*)malloc((size_t)na * n * sizeof(cd));
+  if (!xh || !twf || !twi || !Wx || !dWx) return 2;
+  for (long i = 0; i < n; ++i) xh[n1 + i].re = x[i];
+  for (long i = 0; i < n1; ++i) { long m = n1 - i; if (m < n) xh[i].re = x[m]; }                   /* reflect */
+  for (long i = 0; i < P - n1 - n; ++i) { long m = n - 2 - i; if (m >= 0) xh[n1 + n + i].re = x[m]; }
+  make_tw(twf, P, -1);
+  make_tw(twi, P, +1);
+  fft_inplace(xh, P, twf, NULL);
+  const double h = 2.0 * M_PI / (double)P, norm = 1.0 / (double)P;
+  if (gamma < 0) gamma = 10.0 * 2.220446049250313e-16;
+#pragma omp parallel
+  {
+    cd* a = (cd*)malloc((size_t)P * sizeof(cd));
+    cd* b = (cd*)malloc((size_t)P * sizeof(cd));
+#pragma omp for schedule(dynamic, 1)
+    for (long s = 0; s < na; ++s) {
+      for (long k = 0; k < P; ++k) {
+        const double xi = (k <= P / 2) ? (double)k * h : (double)(k - P) * h;     /* base.rs:18-33 */
+        const double w = scales[s] * xi;
+        double v = 0.0;
+        if (wavelet == 1) {
+          if (w >= 0.0) v = pow(M_PI, -0.25) * M_SQRT2 * (exp(-0.5 * (w - 6.0) * (w - 6.0)) - exp(-18.0) * exp(-0.5 * w * w));
+        } else if (w > 0.0) {
+          v = 2.0 * exp(60.0 * log(w) - pow(w, 3.0));
+        }
+        a[k].re = xh[k].re * v;
+        a[k].im = xh[k].im * v;
+        b[k].re = -a[k].im * (xi / dt);                                            /* (i xi / dt) * a */
+        b[k].im = a[k].re * (xi / dt);
+      }
+      fft_inplace(a, P, twi, NULL);
+      fft_inplace(b, P, twi, NULL);
+      for (long j = 0; j < n; ++j) {
+        Wx[s * n + j].re = a[n1 + j].re * norm;
+        Wx[s * n + j].im = a[n1 + j].im * norm;
+        dWx[s * n + j].re = b[n1 + j].re * norm;
+        dWx[s * n + j].im = b[n1 + j].im * norm;
+      }
+    }
+    free(a);
+    free(b);
+  }
+  /* ssq_cwt.rs:450-469 (maprange "peak", log) */
+  const double fmin = 1.0 / scales[na - 1], fmax = 1.0 / scales[0];
+  const double lmin = log2(fmin), lstep = (log2(fmax) - lmin) / (double)(na - 1);
+  for (long i = 0; i < na; ++i) ssq_freqs[i] = pow(2.0, lmin + (double)i * lstep);
+  const int is_log = ssq_freqs[1] / ssq_freqs[0] > 1.1;                            /* :135-139 */
+  const double bmin = is_log ? log2(ssq_freqs[0]) : ssq_freqs[0];
+  const double bstep = is_log ? (log2(ssq_freqs[na - 1]) - bmin) / (double)(na - 1)
+                              : (ssq_freqs[na - 1] - ssq_freqs[0]) / (double)(na - 1);
+  memset(Tx, 0, (size_t)na * n * 2 * sizeof(double));
+#pragma omp parallel for schedule(static)
+  for (long j = 0; j < n; ++j) {                                                   /* :160-213, one column per task */
+    for (long i = 0; i < na; ++i) {
+      const cd W = Wx[i * n + j], D = dWx[i * n + j];
+      if (hypot(W.re, W.im) < gamma) continue;                                     /* :23-29 */
+      const double w = fabs((D.im * W.re - D.re * W.im) / ((W.re * W.re + W.im * W.im) * 6.283185307179586));
+      if (isinf(w) || isnan(w)) continue;
+      const double v = ((is_log ? log2(w) : w) - bmin) / bstep;
+      const double r = round(v);                                                   /* half away from zero */
+      if (!(r >= 0.0) || r >= (double)na) continue;                                /* dropped (:177, :188) */
+      const long bin = (long)r;
+      const long k = flipud ? na - 1 - bin : bin;
+      Tx[2 * (k * n + j)] += W.re;
+      Tx[2 * (k * n + j) + 1] += W.im;
+    }
+  }
+  free(xh); free(twf); free(twi); free(Wx); free(dWx);
+  return 0;
+}

@@ -73,5 +73,23 @@ def main():
             print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")
 
 
+def make_c2_k_cols():
+    """(vi) oracle bins of BASELINE config 2 on every 16th frame (256 columns), for bench.py's `validation`: the measured
+    end-to-end fp32 bin mismatch rate (SURVEY 8(c) asks to report it).  Input = the fp32 workload signal, seed 0."""
+    x32 = o.synth_signal(1 << 20, 0, np.float32)
+    T, f, im = o.ssq_stft(x32.astype(np.float64), np.hanning(1024), n_fft=1024, hop_len=256, fs=1.0,
+                          return_intermediates=True)
+    cols = np.arange(0, 4096, 16)
+    keep = ~np.isinf(im["w"][:, cols])
+    strong = keep & (np.abs(im["Sx"][:, cols]) > 1e-3 * np.abs(im["Sx"]).max())
+    np.savez_compressed(os.path.join(HERE, "c2_k_cols.npz"), col_index=cols,
+                        k=np.where(keep, im["k"][:, cols], -1).astype(np.int16), strong=np.packbits(strong, axis=None),
+                        shape=np.array(strong.shape))
+    print("c2_k_cols.npz", os.path.getsize(os.path.join(HERE, "c2_k_cols.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "c2k":
+        make_c2_k_cols()
+    else:
+        main()

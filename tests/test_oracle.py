@@ -137,3 +137,15 @@ def test_c2_summary_statistics_match_oracle_run():
     g = _load("c2_summary.npz")
     assert g["col_sums"].shape == (4096,) and g["row_energy"].shape == (513,) and g["k_hist"].sum() > 2_000_000
     assert float(g["sx_absmax"]) > 100
+
+
+def test_c_restatement_of_ssq_cwt_matches_numpy_oracle():
+    """oracle/ssq_ref.c::ssq_ref_ssq_cwt (bench.py's cpu_baseline of the C4 leg) against oracle.ssq_cwt: same
+    frequencies, same bins (identical Tx up to summation rounding), both wavelets, the linear-formula quirk included."""
+    from oracle import ref_c
+    x = o.synth_signal(3000, 1, np.float64)
+    for wavelet, sc in (("morlet", 2.0 ** np.linspace(1, 9, 40)), ("gmw", np.logspace(1, 3, 12) / 10)):
+        T, f = ref_c.ssq_cwt(x, sc, wavelet=wavelet)
+        To, fo = o.ssq_cwt(x, wavelet=wavelet, scales=sc)
+        assert np.array_equal(f, fo)
+        assert np.abs(T - To).max() <= 1e-12 * np.abs(To).max()

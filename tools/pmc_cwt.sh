@@ -29,7 +29,6 @@ for f in glob.glob("$OUT/pass*/**/*counter_collection.csv", recursive=True):
             agg[(name + " grid=" + r.get("Grid_Size", "?"), r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
     for (k, c), v in sorted(agg.items()):
-        if len(v) < 8 and "reassign" not in k: continue
         line = f"{k:55s} {c:26s} n={len(v):4d} mean={sum(v)/len(v):.6g}"
         print(line); o.write(line + "\n")
 PY
