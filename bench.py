@@ -39,7 +39,7 @@ if ROOT not in sys.path:
 
 HBM_MEASURED_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: HBM3E 6.29 TB/s measured (float4 copy)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def parse_args(argv=None):
