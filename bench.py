@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--settle-ms", type=float, default=80.0,
                     help="untimed run-in of the same step before the W warm-up steps (reported as settle_ms): the first "
                          "~30 ms of this kernel after any gap run 5-8 %% slower than its steady state (clock ramp)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the fp64 BASELINE-config-5 secondary legs (17 - 170 GB)")
     ap.add_argument("--gather", action="store_true", help="also time the optional RCCL all_gather of the Tx shards")
     return ap.parse_args(argv)
 
@@ -351,49 +352,65 @@ def roofline_of(leg, kern_ms, traffic, kernel_name):
             "alg_bytes_per_launch": alg}
 
 
-def cwt_c4_leg(lib, _lib, steps=5, cpu=True):
-    """BASELINE config 4 through the plan API (tools/bench_cwt.py is the full tool): ms per call, bins/s and the
-    algorithmic-bytes fraction of the HBM roof; traffic from the committed PMC passes if present."""
+FP_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}            # MI355X_MICROARCH.md: vector fp32 / fp64
+
+
+def cwt_leg(lib, _lib, f32, log2n, batch, steps, golden, cpu, traffic_files=(), label=""):
+    """ssq_cwt (Morlet, 256 log scales 2**linspace(1, log2n - 1, 256)) through the plan API on `batch` signals of 2^log2n
+    samples: ms per call, bins/s, BOTH rooflines (algorithmic bytes against HBM, the transforms' flops against the vector
+    roof), the measured traffic of the committed PMC passes if present, and a check of signal 0 of what was timed against
+    the committed oracle summary (block sums of the column sums -- invariant under bin flips --, row energies, the norm:
+    the quantities tests/test_gpu_cwt_full.py checks)."""
     import ctypes as C
     from ssqueeze_rs_amd.synth import synth_signal
-    N, na = 1 << 20, 256
-    scales = 2.0 ** np.linspace(1, 19, na)
+    N, na = 1 << log2n, 256
+    es = 4 if f32 else 8
+    rdt, cdt = (np.float32, np.complex64) if f32 else (np.float64, np.complex128)
+    scales = 2.0 ** np.linspace(1, log2n - 1, na)
     plan, dx, dT, ws = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-    _lib.check(lib.ssq_cwt_plan_create(C.byref(plan), _lib.SSQ_F32, N, _lib.WAVELET["morlet"],
+    _lib.check(lib.ssq_cwt_plan_create(C.byref(plan), _lib.SSQ_F32 if f32 else _lib.SSQ_F64, N, _lib.WAVELET["morlet"],
                                        scales.ctypes.data_as(C.c_void_p), na, 1.0, 0))
-    wsb = lib.ssq_cwt_plan_workspace_bytes(plan, 1)
+    wsb = lib.ssq_cwt_plan_workspace_bytes(plan, batch)
+    plane = na * N * 2 * es
     try:
-        _lib.check(lib.ssq_dev_malloc(C.byref(dx), N * 4))
-        _lib.check(lib.ssq_dev_malloc(C.byref(dT), na * N * 8))
+        _lib.check(lib.ssq_dev_malloc(C.byref(dx), batch * N * es))
+        _lib.check(lib.ssq_dev_malloc(C.byref(dT), batch * plane))
         _lib.check(lib.ssq_dev_malloc(C.byref(ws), wsb))
-        x = synth_signal(N, 0, np.float32)
+        x = np.concatenate([synth_signal(N, b, rdt) for b in range(batch)])
         _lib.check(lib.ssq_memcpy_h2d(dx, x.ctypes.data_as(C.c_void_p), x.nbytes, None))
 
         def run():
-            _lib.check(lib.ssq_cwt_plan_exec_ssq(plan, dx, 1, 0, 0, 0, 1, -1.0, dT, None, None, None, ws, wsb, None))
+            _lib.check(lib.ssq_cwt_plan_exec_ssq(plan, dx, batch, 0, 0, 0, 1, -1.0, dT, None, None, None, ws, wsb, None))
             _lib.check(lib.ssq_device_sync())
 
         run()
-        # what is timed is checked: the result against the committed oracle summary of C4 (tests/golden/c4_summary.npz,
-        # the quantities tests/test_gpu_cwt_full.py checks: block sums of the column sums -- invariant under bin flips --,
-        # row energies, the norm)
         check = {"validated": None}
-        gpath = os.path.join(ROOT, "tests", "golden", "c4_summary.npz")
-        if os.path.exists(gpath):
+        gpath = os.path.join(ROOT, "tests", "golden", golden) if golden else None
+        if gpath and os.path.exists(gpath):
             g = np.load(gpath)
-            Tx = np.empty((na, N), dtype=np.complex64)
-            _lib.check(lib.ssq_memcpy_d2h(Tx.ctypes.data_as(C.c_void_p), dT, Tx.nbytes, None))
-            _lib.check(lib.ssq_device_sync())
             nb = g["block_col_sums"].shape[0]
-            blk = Tx.sum(0, dtype=np.complex128).reshape(nb, N // nb).sum(1)
+            col = np.zeros(N, dtype=np.complex128)
+            row = np.zeros(na, dtype=np.float64)
+            sq = 0.0
+            rows_per = max(1, (1 << 30) // (N * 2 * es))           # <= 1 GiB of host memory per piece (C5: 17 GB per signal)
+            for r0 in range(0, na, rows_per):
+                r1 = min(na, r0 + rows_per)
+                part = np.empty((r1 - r0, N), dtype=cdt)
+                _lib.check(lib.ssq_memcpy_d2h(part.ctypes.data_as(C.c_void_p), C.c_void_p(dT.value + r0 * N * 2 * es),
+                                              part.nbytes, None))
+                _lib.check(lib.ssq_device_sync())
+                col += part.sum(0, dtype=np.complex128)
+                row[r0:r1] = np.abs(part).sum(1, dtype=np.float64)
+                sq += float((part.real.astype(np.float64) ** 2).sum() + (part.imag.astype(np.float64) ** 2).sum())
+                del part
+            blk = col.reshape(nb, N // nb).sum(1)
             e_blk = float(np.abs(blk - g["block_col_sums"]).max() / np.abs(g["block_col_sums"]).max())
-            e_row = float(np.abs(np.abs(Tx).sum(1, dtype=np.float64) - g["row_energy"]).max() / g["row_energy"].max())
-            nrm = float(np.sqrt((Tx.real.astype(np.float64) ** 2 + Tx.imag.astype(np.float64) ** 2).sum()))
-            e_nrm = abs(nrm - float(g["norm2"])) / float(g["norm2"])
-            check = {"validated": bool(e_blk <= 2e-4 and e_row <= 1e-3 and e_nrm <= 1e-4),
-                     "validation": {"block_colsum_relerr": e_blk, "row_energy_relerr": e_row, "norm_relerr": e_nrm,
-                                    "golden": "tests/golden/c4_summary.npz"}}
-            del Tx
+            e_row = float(np.abs(row - g["row_energy"]).max() / g["row_energy"].max())
+            e_nrm = abs(float(np.sqrt(sq)) - float(g["norm2"])) / float(g["norm2"])
+            tol = (2e-4, 1e-3, 1e-4) if f32 else (1e-9, 1e-6, 1e-7)
+            check = {"validated": bool(e_blk <= tol[0] and e_row <= tol[1] and e_nrm <= tol[2]),
+                     "validation": {"signal": 0, "block_colsum_relerr": e_blk, "row_energy_relerr": e_row,
+                                    "norm_relerr": e_nrm, "golden": "tests/golden/" + golden}}
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
@@ -403,15 +420,21 @@ def cwt_c4_leg(lib, _lib, steps=5, cpu=True):
             if ptr:
                 lib.ssq_dev_free(ptr)
         lib.ssq_cwt_plan_destroy(plan)
-    alg = 4 * N + 8 * na * N
-    out = {"workload": "ssq_cwt morlet, 256 log scales, 1 x 2^20, fp32", "ms_per_call": dt * 1e3, **check,
-           "value": na * N / dt, "unit": "TF-bins/s", "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
-           "workspace_GB": wsb / 1e9}
-    for name in ("r03_cwt_traffic.json", "r02_cwt_traffic.json"):
+    alg = batch * (es * N + 2 * es * na * N)                       # x in once, Tx out once
+    P = 1 << int(np.ceil(np.log2(N + N // 2)))
+    flops = batch * (1 + 2 * na) * 5.0 * P * np.log2(P)            # (1 + 2 na) transforms of length P
+    out = {"workload": f"ssq_cwt morlet, 256 log scales, {batch} x 2^{log2n}, {'fp32' if f32 else 'fp64'}" + label,
+           "ms_per_call": dt * 1e3, **check,
+           "value": batch * na * N / dt, "unit": "TF-bins/s", "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS,
+           "roofline_vector": {"bound": "valu", "achieved": flops / dt / 1e12, "unit": "TFLOP/s",
+                               "peak": FP_PEAK_TFLOPS["f32" if f32 else "f64"],
+                               "frac": flops / dt / 1e12 / FP_PEAK_TFLOPS["f32" if f32 else "f64"]},
+           "device_footprint_GB": (batch * plane + wsb + batch * N * es) / 1e9, "workspace_GB": wsb / 1e9}
+    for name in traffic_files:
         tf = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tf):
             with open(tf) as fh:
-                out["traffic_over_algorithmic"] = json.load(fh)["total_GB_per_call"] * 1e9 / alg
+                out["traffic_over_algorithmic"] = json.load(fh)["total_GB_per_call"] * 1e9 / (alg / batch)
             out["traffic_source"] = "profiles/" + name
             break
     if cpu:
@@ -530,9 +553,21 @@ def main():
         l64.close()
         # (3) BASELINE config 4: ssq_cwt, 1 x 2^20, 256 log scales, Morlet, fp32 (wall clock around synchronised calls)
         try:
-            sec["c4_ssq_cwt_f32"] = cwt_c4_leg(lib, _lib, cpu=not args.no_cpu_baseline)
+            sec["c4_ssq_cwt_f32"] = cwt_leg(lib, _lib, True, 20, 1, 5, "c4_summary.npz", not args.no_cpu_baseline,
+                                             ("r03_cwt_traffic.json", "r02_cwt_traffic.json"))
         except Exception as e:                                    # a secondary leg must not take the headline down
             sec["c4_ssq_cwt_f32"] = {"error": str(e)}
+        # (4) BASELINE config 5 in the reference's own arithmetic: ONE fp64 signal of 2^22 samples (its 17.2 GB of Tx
+        #     checked against the committed oracle summary), then C5's per-GPU share -- 8 signals, 137 GB of Tx plus the
+        #     plan's scratch resident at once -- run once to prove the footprint DESIGN.md section 3 claims
+        if not args.no_c5:
+            for key, nb, st, gold, lab in (("c5_one_signal_f64", 1, 2, "c5_summary.npz", ""),
+                                           ("c5_share_8_signals_f64", 8, 1, "c5_summary.npz",
+                                            " (BASELINE config 5's share of one of 8 GPUs)")):
+                try:
+                    sec[key] = cwt_leg(lib, _lib, False, 22, nb, st, gold, False, ("r03_cwt_traffic_f64.json",), lab)
+                except Exception as e:
+                    sec[key] = {"error": str(e)}
 
     gather = None
     if args.gather and use_dist:

@@ -926,7 +926,11 @@ int ssq_cwt_plan_create_v(ssq_cwt_plan** plan, int dtype, int64_t n_signal, int 
   } else {
     pl->two_step = true;
     pl->log_p2 = lp / 2;                                          // step B gets the shorter transforms (two blocks per CU)
-    if (const char* e = tune_env("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch (default 0)
+    // fp64: a tile of step A holds C = 160 KB / (17 M bytes) columns, i.e. 16 C-byte global segments -- the SHORTER first
+    // step doubles them (C5: 4096 -> 2048 points, 32 -> 64 B; C4: 2048 -> 1024, 64 -> 128 B): one C5 signal 106 -> 91 ms,
+    // C4 fp64 19.0 -> 17.2 ms (profiles/r03_ab_cwt_f64_split.txt)
+    if (dtype == SSQ_F64) pl->log_p2 = (lp + 1) / 2;
+    if (const char* e = tune_env("SSQ_CWT_P2UP")) pl->log_p2 = (lp + std::atoi(e)) / 2;   // tuning switch
     pl->log_p1 = lp - pl->log_p2;
   }
   // SSQ_CWT_REG=0 keeps the tile kernels for the two-step scales (A/B and tests)

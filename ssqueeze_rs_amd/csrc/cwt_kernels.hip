@@ -165,14 +165,13 @@ void cwt_tile_kernel(CwtDev<T> p) {
 
   const int tid = threadIdx.x;
   const int tr = blockIdx.y;
-#ifdef SSQ_CWT_XCD
-  // blocks go round-robin over the 8 XCDs: give each XCD a contiguous range of tiles, so that the neighbouring
-  // tiles whose sub-line segments share cache lines meet in one L2
-  const long long tile = (gridDim.x % 8 == 0) ? (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
-                                              : (long long)blockIdx.x;
-#else
-  const long long tile = blockIdx.x;
-#endif
+  // blocks go round-robin over the 8 XCDs: give each XCD a contiguous range of tiles, so that the neighbouring tiles
+  // whose SUB-LINE segments share 128-byte lines meet in one L2 and leave it as whole lines.  fp64 only: its tiles hold
+  // 2 - 8 columns = 32 - 128-byte segments (C5: 106 -> 92 ms, with the shorter step A 86 ms); fp32 tiles are whole lines
+  // already and measured no gain (round 1)
+  const long long tile = (sizeof(T) == 8 && gridDim.x % 8 == 0)
+                             ? (long long)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8
+                             : (long long)blockIdx.x;
   const long long P2 = 1LL << p.log_p2;
   const long long P1 = 1LL << p.log_p1;
   const long long t0 = tile * C;                        // first column (A) / row (B) / residue (Z) / transform (S)
