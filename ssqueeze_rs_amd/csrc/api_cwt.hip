@@ -486,6 +486,18 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
         p.n_transforms = ns * p.n_kinds;
         if (pl->reg) {
           SSQ_HIP(launch_cwt_reg_inv(reg_dev<T>(pl, p), pl->n_cus, st));
+        } else if (ns == 1 && p.n_kinds == 2 && 2 * pl->P * (long long)sizeof(cpx<T>) > (192LL << 20)) {
+          // one scale's TWO step buffers do not fit the 256 MB Infinity Cache (fp64 at P = 2^23: 268 MB): run the kinds one
+          // after the other through ONE buffer (134 MB), so that step B reads what step A just wrote from the cache
+          for (int kind = 0; kind < 2; ++kind) {
+            p.tr0 = kind;
+            p.n_transforms = 1;
+            p.tw_m = (const cpx<T>*)pl->d_tw1;
+            SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));
+            p.tw_m = (const cpx<T>*)pl->d_tw2;
+            SSQ_HIP(launch_cwt_tile<T>(CWT_INV_B, p, st));
+          }
+          p.tr0 = 0;
         } else {
           p.tw_m = (const cpx<T>*)pl->d_tw1;
           SSQ_HIP(launch_cwt_tile<T>(CWT_INV_A, p, st));

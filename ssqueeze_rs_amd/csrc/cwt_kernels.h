@@ -42,6 +42,8 @@ struct CwtDev {
   int scale0;            // first scale of this chunk
   int n_kinds;           // 1 (Wx) or 2 (Wx and dWx)
   int n_transforms;      // transforms in this launch (chunk scales * kinds; 1 for forward)
+  int tr0;               // tile kernels: logical index of the launch's first transform (kind = (tr0 + y) % n_kinds); the
+                         // step buffer is indexed by the launch-local y (one kind at a time when two would not fit the cache)
   T xi_step;             // (2*pi/P)/dt : xi_k/dt = k * xi_step      (wavelets/base.rs:18-33, cwt.rs:207)
 };
 

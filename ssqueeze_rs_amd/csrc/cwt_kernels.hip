@@ -164,7 +164,8 @@ void cwt_tile_kernel(CwtDev<T> p) {
   cpx<T>* f1 = reinterpret_cast<cpx<T>*>(smem + K::LDS_BYTES);
 
   const int tid = threadIdx.x;
-  const int tr = blockIdx.y;
+  const int ty = blockIdx.y;                 // launch-local transform: indexes the step buffer
+  const int tr = p.tr0 + ty;                 // logical transform: scale and kind
   // blocks go round-robin over the 8 XCDs: give each XCD a contiguous range of tiles, so that the neighbouring tiles
   // whose SUB-LINE segments share 128-byte lines meet in one L2 and leave it as whole lines.  fp64 only: its tiles hold
   // 2 - 8 columns = 32 - 128-byte segments (C5: 106 -> 92 ms, with the shorter step A 86 ms); fp32 tiles are whole lines
@@ -197,7 +198,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
       return conj_if(load_spectrum(p, tr, n), true);
     } else if constexpr (stepB) {
       // step A already left it conjugated
-      return p.ybuf[(long long)tr * p.P + (t0 + e / M) * P2 + (e % M)];
+      return p.ybuf[(long long)ty * p.P + (t0 + e / M) * P2 + (e % M)];
     } else if constexpr (stepZ) {
       const int k = e % M;
       long long d = t0 + e / M;
@@ -308,7 +309,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
       if ((SSQ_CWT_ABL & 4) && buf[u].x != (T)12345.678) continue;   // ablation: compute, do not write
       if constexpr (stepA) {
         const int c = e % C, k1 = e / C;
-        p.ybuf[(long long)tr * p.P + (long long)k1 * P2 + t0 + c] = buf[u];
+        p.ybuf[(long long)ty * p.P + (long long)k1 * P2 + t0 + c] = buf[u];
       } else if constexpr (stepB || stepZ) {
         const int c = e % C, k2 = e / C;
         if (stepZ && t0 + c >= P1) continue;
