@@ -113,3 +113,9 @@ def gmw_center_frequency(gamma: float = 3.0, beta: float = 60.0, kind: str = "pe
 # intermediates; `_upstream=True` on stft / ssq_stft / cwt / ssq_cwt runs the numerics of the vendored upstream
 # ssqueezepy.  `ssqueeze_rs_amd.upstream` mirrors upstream's own signatures and adds the inverses
 # istft / issq_stft / icwt / issq_cwt.
+
+# fp32 `cwt` (with derivative) / `ssq_cwt` run the scales whose wavelet is short in time on TIME TILES by default
+# (csrc/cwt_os.hip): the plain and decimated tiles evaluate the same convolution with the wavelet's time response cut at
+# the tile halo -- an approximation below 1e-5 of each row's maximum (tests pin the eligibility limits); the full-circle
+# blocks and analytic-input tiles are exact.  SSQ_CWT_OS=0 / SSQ_CWT_OS_STORE=0 select the exact frequency-domain path;
+# float64 always takes it.

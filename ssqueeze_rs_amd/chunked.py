@@ -11,15 +11,18 @@ samples on both sides -- the neighbours' samples inside the array, the boundary 
 are concatenated along the frames axis.  depth = n_fft for the STFT family (:216), max(1024, samples // 10) for the
 CWT family (ssq_cwt_test.py:118-120).
 
-Here the channels are uploaded once, the halos live on the device, all (channel, chunk) windows run as ONE strided
-batch through the plan (no Python loop over channels, no padded copies) and the stacking is a device pass:
+Here the channels are uploaded once, the halos live on the device and the stacking is a device pass.  STFT family: all
+(channel, chunk) windows run as ONE strided batch through the plan (no Python loop over channels, no padded copies).
+CWT family: the windows are contiguous views of the same device array too, but every (channel, chunk) is its own
+batch-1 plan exec (a Python loop of launches, no host copies in between):
 `include/ssq_hip.h`: ssq_chunk_halo_fill, ssq_stft_plan_exec_strided, ssq_chunks_relayout.
 
 `trim`: what is kept of every extended chunk's output --
   "none"  everything `process_chunk` returns (the reference function's own output, chunk by chunk);
-  "halo"  only the columns whose frame start / time sample lies inside the chunk proper: with depth a multiple of
-          the hop the concatenation is then the whole-signal frame grid, and away from the two array ends it is
-          bitwise the whole-signal transform (the seams vanish; Dask's own trimming is meant to do this).
+  "halo"  only the columns whose frame start / time sample lies inside the chunk proper: with depth AND chunk multiples
+          of the hop (the default chunk of 1 000 000 is not one of 256: pass e.g. chunk=2**20) the concatenation is then
+          the whole-signal frame grid, and away from the two array ends it is bitwise the whole-signal transform (the
+          seams vanish; Dask's own trimming is meant to do this).
 """
 from __future__ import annotations
 
@@ -142,9 +145,9 @@ def _stft_family(data, out_kind, fs, n_fft, hop, window, squeezing, chunk, depth
             slab = max(1, min(len(idx), temp_bytes // max(per, 1)))
             ws = int(lib.ssq_stft_plan_workspace_bytes(plan, Cn * slab, out_kind))
             d_ws = C.c_void_p()
-            _lib.check(lib.ssq_dev_malloc(C.byref(d_tmp), slab * per))
-            _lib.check(lib.ssq_dev_malloc(C.byref(d_ws), max(ws, 16)))
-            try:
+            try:                                             # (allocations inside: a failing one must not leak the other)
+                _lib.check(lib.ssq_dev_malloc(C.byref(d_tmp), slab * per))
+                _lib.check(lib.ssq_dev_malloc(C.byref(d_ws), max(ws, 16)))
                 for a in range(0, len(idx), slab):           # consecutive equal-length chunks: one strided batch
                     js = idx[a:a + slab]
                     J = len(js)
@@ -234,10 +237,10 @@ def _cwt_family(data, ssq, fs, wavelet, scales, nv, padtype, squeezing, maprange
             slab = max(1, min(len(idx), temp_bytes // max(per, 1)))
             d_ws = C.c_void_p()
             tmps = [C.c_void_p() for _ in range(n_out)]
-            _lib.check(lib.ssq_dev_malloc(C.byref(d_ws), max(wsb, 16)))
-            for t in tmps:
-                _lib.check(lib.ssq_dev_malloc(C.byref(t), slab * per))
-            try:
+            try:                                             # (allocations inside: a failing one must not leak the others)
+                _lib.check(lib.ssq_dev_malloc(C.byref(d_ws), max(wsb, 16)))
+                for t in tmps:
+                    _lib.check(lib.ssq_dev_malloc(C.byref(t), slab * per))
                 if ssq and freqs is None:
                     freqs = np.empty(na, dtype=np.float64)
                     _lib.check(lib.ssq_cwt_ssq_freqs(sc.ctypes.data_as(C.c_void_p), na, n_ext, dt,

@@ -478,3 +478,26 @@ def test_cwt_short_wavelet_scales_by_storing_tiles(l1_norm, monkeypatch):
     for j, i in enumerate(sub):
         assert np.abs(Wx[i] - Wx_o[j]).max() <= 2e-5 * np.abs(Wx_o[j]).max(), i
         assert np.abs(dWx[i] - dWx_o[j]).max() <= 2e-5 * np.abs(dWx_o[j]).max(), i
+
+
+@pytest.mark.parametrize("wavelet,a_lo,a_hi", [("morlet", 4.0, 2048.0 / 6.0), ("gmw", 1.3, 2048.0 / (6.0 * 4.943))])
+def test_time_tile_eligibility_limits_are_pinned(wavelet, a_lo, a_hi, monkeypatch):
+    """the plain time tiles cut the wavelet's time response at the tile halo (6 sigma_t <= 2048 samples,
+    sigma_t = a for the Morlet wavelet, 4.943 a for the GMW) and need psih negligible at Nyquist (a >= 4 / 1.3): the
+    eligibility limits of csrc/api_cwt.hip.  Scales EXACTLY at both limits (and just outside them, which must take the
+    exact frequency-domain path) against that path: the truncated tail stays below 1e-5 of each row's maximum, so a later
+    change of the thresholds cannot silently widen the error."""
+    N = 1 << 18                                            # >= 64 tiles of 4096: the family is on
+    x = _sig(N, 83, np.float32)
+    inside = np.geomspace(a_lo, a_hi, 12)                  # first and last ARE the limits
+    scales = np.concatenate([[a_lo * 0.97], inside, [a_hi * 1.03]])
+    Wx, _, dWx = _rs.cwt(x, wavelet=wavelet, scales=scales, derivative=True)
+    monkeypatch.setenv("SSQ_CWT_OS_STORE", "0")
+    Wx0, _, dWx0 = _rs.cwt(x, wavelet=wavelet, scales=scales, derivative=True)
+    tiled = [i for i in range(len(scales)) if not np.array_equal(Wx[i], Wx0[i])]
+    assert 1 in tiled and len(scales) - 2 in tiled, tiled   # the limits themselves are tiled ...
+    assert 0 not in tiled and len(scales) - 1 not in tiled  # ... the scales just outside are not
+    for a, b in ((Wx, Wx0), (dWx, dWx0)):
+        row_max = np.abs(b).max(axis=1, keepdims=True)
+        err = (np.abs(a - b) / row_max).max(axis=1)
+        assert err.max() <= 1e-5, err
