@@ -838,6 +838,8 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
         float4* __restrict__ og4 = reinterpret_cast<float4*>(p.out + rsig * (long long)NF * p.n_frames + rframe0 + 2 * fp +
                                                              (long long)k0 * p.n_frames);
         const long long gstep4 = (long long)RS2 * p.n_frames / 2;     // in float4 units
+        // (round 3: a wave-uniform base + 32-bit per-thread offset does not make the compiler take the SGPR-base store form --
+        //  loop strength reduction rebuilds the 64-bit vector address chain either way)
         const T sc0 = col_scale[2 * fp], sc1 = col_scale[2 * fp + 1];
         long long* tc = reinterpret_cast<long long*>(tile_re) + k0 * PITCH + 2 * fp;
         auto sweep2 = [&](int j) {
@@ -1156,8 +1158,11 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
         const float den = S.x * S.x + S.y * S.y;
         const float num = dS.y * S.x - dS.x * S.y;
         const float pd = num * __builtin_amdgcn_rcpf(den * p.two_pi_eff);
-        const float w = fabsf((sfs0 + (float)q * sfs_q) - pd);
-        float m = fma_clamp01(den, p.keep_big, p.keep_bias) * fma_clamp01(w, 0.0f, 1.0f);
+        // d = Sfs - pd; w = |d| (ssq_stft.rs:33) is only ever used through modifiers: the finiteness mask ignores the sign and
+        // the bin fma takes -|d| (round 3: nine v_and per frame less -- those do not pair with another wave's instruction)
+        const float d = (sfs0 + (float)q * sfs_q) - pd;
+        const float w = fabsf(d);
+        float m = fma_clamp01(den, p.keep_big, p.keep_bias) * fma_clamp01(d, 0.0f, 1.0f);
         if (EDGE) m *= lane_on;
         if (q == 8) m *= (t == 0) ? 1.0f : 0.0f;
         const cpx<T> c = LEB ? cpx<T>{p.leb_unit * m, 0.0f} : cpx<T>{S.x * m, S.y * m};
