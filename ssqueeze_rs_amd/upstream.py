@@ -230,9 +230,16 @@ def _issq(Tx, scale, row_scale=None):
 
 
 # ---------------------------------------------------------------------------------------------------- CWT family ----
-def cwt(x, wavelet="gmw", scales=None, fs=None, t=None, nv=None, l1_norm=True, derivative=False, padtype="reflect",
-        rpadded=False):
-    """ssqueezepy.cwt (old/ssqueezepy/_cwt.py:12-318) with explicit scales -> (Wx, scales[, dWx])."""
+def cwt(x, wavelet="gmw", scales="log-piecewise", fs=None, t=None, nv=32, l1_norm=True, derivative=False,
+        padtype="reflect", rpadded=False, vectorized=True, astensor=True, cache_wavelet=None, order=0, average=None,
+        nan_checks=None, patience=0):
+    """ssqueezepy.cwt (old/ssqueezepy/_cwt.py:12-318) -> (Wx, scales[, dWx]).  `scales` must be an explicit array (the
+    default string asks for upstream's automatic bounds, which are not built); `vectorized`, `astensor`, `cache_wavelet`,
+    `nan_checks`, `patience` select code paths with identical numbers upstream and are accepted and unused."""
+    if order != 0 or average is not None:
+        raise ValueError("higher-order GMWs (`order`, `average`) are not built")
+    if isinstance(scales, np.ndarray):
+        nv = None                                            # _cwt.py:226-227
     lib = _lib.load()
     xa, batched, code = _signal(x)
     batch, N = xa.shape
@@ -276,7 +283,7 @@ def _ssq_freqs(s, N, wcode, p0, p1, dt, maprange, scaletype):
     raise ValueError(f"ssq_freqs {scaletype!r}: 'log' and 'linear' are built")
 
 
-def ssq_cwt(x, wavelet="gmw", scales=None, nv=None, fs=None, t=None, ssq_freqs=None, padtype="reflect",
+def ssq_cwt(x, wavelet="gmw", scales="log-piecewise", nv=None, fs=None, t=None, ssq_freqs=None, padtype="reflect",
             squeezing="sum", maprange="peak", difftype="trig", difforder=None, gamma=None, vectorized=True,
             preserve_transform=None, astensor=True, order=0, nan_checks=None, patience=0, flipud=True,
             cache_wavelet=None, get_w=False, get_dWx=False):
@@ -325,8 +332,8 @@ def issq_cwt(Tx, wavelet="gmw", cc=None, cw=None):
     return _issq(Tx, 2.0 / adm_ssq(wavelet))
 
 
-def icwt(Wx, wavelet="gmw", scales=None, nv=None, one_int=True, x_len=None, x_mean=0, padtype="reflect", rpadded=False,
-         l1_norm=True):
+def icwt(Wx, wavelet="gmw", scales="log-piecewise", nv=None, one_int=True, x_len=None, x_mean=0, padtype="reflect",
+         rpadded=False, l1_norm=True):
     """ssqueezepy.icwt (old/ssqueezepy/_cwt.py:321-452), one-integral form on exponential scales:
     (2 / Cpsi) ln(2^(1/nv)) sum_a Re Wx[a] / (1 or sqrt(a))  + x_mean."""
     if not one_int:

@@ -119,3 +119,45 @@ def test_pinned_empty_falls_back_to_pageable_memory(monkeypatch):
     monkeypatch.setattr(_lib, "PINNED_RESULT_LIMIT", 16)
     b = _lib.pinned_empty((4, 4), np.float64)            # 128 B > limit: the pool is not even asked
     assert b.shape == (4, 4) and calls == []
+
+
+def test_upstream_mirror_signatures_match_ssqueezepy():
+    """`ssqueeze_rs_amd.upstream` mirrors the vendored upstream's callables: parameter names, order and
+    defaults as written at old/ssqueezepy/_stft.py:13-14, :184-185, _ssq_stft.py:13-16, :139-140, _cwt.py:12-15, :321-322,
+    _ssq_cwt.py:12-17, :313.  Decided before the GPU is touched: options outside the built subset raise ValueError."""
+    from ssqueeze_rs_amd import upstream as up
+
+    def sig(fn):
+        return [(k, v.default) for k, v in inspect.signature(fn).parameters.items()][1:]
+
+    assert sig(up.stft) == [("window", None), ("n_fft", None), ("win_len", None), ("hop_len", 1), ("fs", None),
+                            ("t", None), ("padtype", "reflect"), ("modulated", True), ("derivative", False),
+                            ("dtype", None)]
+    assert sig(up.istft) == [("window", None), ("n_fft", None), ("win_len", None), ("hop_len", 1), ("N", None),
+                             ("modulated", True), ("win_exp", 1)]
+    assert sig(up.ssq_stft) == [("window", None), ("n_fft", None), ("win_len", None), ("hop_len", 1), ("fs", None),
+                                ("t", None), ("modulated", True), ("ssq_freqs", None), ("padtype", "reflect"),
+                                ("squeezing", "sum"), ("gamma", None), ("preserve_transform", None), ("dtype", None),
+                                ("astensor", True), ("flipud", False), ("get_w", False), ("get_dWx", False)]
+    assert sig(up.issq_stft) == [("window", None), ("cc", None), ("cw", None), ("n_fft", None), ("win_len", None),
+                                 ("hop_len", 1), ("modulated", True)]
+    assert sig(up.cwt) == [("wavelet", "gmw"), ("scales", "log-piecewise"), ("fs", None), ("t", None), ("nv", 32),
+                           ("l1_norm", True), ("derivative", False), ("padtype", "reflect"), ("rpadded", False),
+                           ("vectorized", True), ("astensor", True), ("cache_wavelet", None), ("order", 0),
+                           ("average", None), ("nan_checks", None), ("patience", 0)]
+    assert sig(up.icwt) == [("wavelet", "gmw"), ("scales", "log-piecewise"), ("nv", None), ("one_int", True),
+                            ("x_len", None), ("x_mean", 0), ("padtype", "reflect"), ("rpadded", False), ("l1_norm", True)]
+    assert sig(up.ssq_cwt) == [("wavelet", "gmw"), ("scales", "log-piecewise"), ("nv", None), ("fs", None), ("t", None),
+                               ("ssq_freqs", None), ("padtype", "reflect"), ("squeezing", "sum"), ("maprange", "peak"),
+                               ("difftype", "trig"), ("difforder", None), ("gamma", None), ("vectorized", True),
+                               ("preserve_transform", None), ("astensor", True), ("order", 0), ("nan_checks", None),
+                               ("patience", 0), ("flipud", True), ("cache_wavelet", None), ("get_w", False),
+                               ("get_dWx", False)]
+    assert sig(up.issq_cwt) == [("wavelet", "gmw"), ("cc", None), ("cw", None)]
+    x = np.zeros(64)
+    for call in (lambda: up.cwt(x), lambda: up.ssq_cwt(x), lambda: up.cwt(x, "bump", scales=2.0 ** np.arange(1, 5.0)),
+                 lambda: up.stft(x, "hann"), lambda: up.ssq_cwt(x, scales=np.array([1.0, 2.0, 5.0])),
+                 lambda: up.issq_stft(np.zeros((33, 64), complex), np.hanning(64), hop_len=2),
+                 lambda: up.cwt(x, scales=2.0 ** np.arange(1, 5.0), order=1)):
+        with pytest.raises(ValueError):
+            call()
