@@ -256,3 +256,31 @@ def test_rs_functions_take_the_upstream_switch():
     T2, f2 = _rs.ssq_cwt(x, "gmw", nv=8, _upstream=True)
     To2, _, fo2, _ = u.ssq_cwt(x, "gmw", scales=sc)
     assert np.allclose(f2, fo2, rtol=1e-14) and np.abs(T2.sum(0) - To2.sum(0)).max() <= 1e-9 * np.abs(To2).max() * len(sc)
+
+
+def test_edge_shapes():
+    """Tiny and ragged inputs: n_fft 2 / 3 (odd) / 8, hop > n_fft, hop = n_fft, N barely above n_fft, N = 1, an all-zero
+    signal (every bin below gamma), N smaller than the padded wavelet support, two scales, a non-power-of-two N with an
+    uneven p2up split -- all against the restatement."""
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(50)
+    win = np.hanning(16)
+    for kw, w in ((dict(n_fft=16, hop_len=4), win), (dict(n_fft=2, hop_len=1), np.ones(2)),
+                  (dict(n_fft=3, hop_len=2), np.hanning(5)[1:4]), (dict(n_fft=16, hop_len=20), win)):
+        assert np.abs(up.stft(x, w, **kw) - u.stft(x, w, **kw)).max() <= 1e-13
+    assert np.abs(up.stft(x[:17], win, n_fft=16, hop_len=4) - u.stft(x[:17], win, n_fft=16, hop_len=4)).max() <= 1e-13
+    assert up.stft(x[:1], win, n_fft=16).shape == (9, 1)
+    assert np.abs(up.ssq_stft(x, np.hanning(8), n_fft=8)[0] - u.ssq_stft(x, np.hanning(8), n_fft=8)[0]).max() <= 1e-13
+    So = u.stft(x, win, n_fft=16, hop_len=8)
+    assert np.abs(up.istft(So, win, n_fft=16, hop_len=8, N=50) - u.istft(So, win, n_fft=16, hop_len=8, N=50)).max() <= 1e-13
+    assert np.abs(up.ssq_stft(np.zeros(64), win, n_fft=16)[0]).max() == 0.0
+    sc = 2.0 ** (np.arange(8, 24) / 8)
+    assert np.abs(up.cwt(x[:20], "gmw", scales=sc)[0] - u.cwt(x[:20], "gmw", scales=sc)[0]).max() <= 1e-13
+    assert up.cwt(x[:3], "gmw", scales=sc)[0].shape == (16, 3)
+    assert np.abs(up.ssq_cwt(np.zeros(64), "morlet", scales=sc)[0]).max() == 0.0
+    xx = rng.standard_normal(1001)                       # p2up(1001) = 2048 with n1 = 524, n2 = 523
+    a = up.ssq_cwt(xx, ("gmw", {"beta": 12}), scales=sc)[0]
+    b = u.ssq_cwt(xx, ("gmw", {"beta": 12}), scales=sc)[0]
+    assert np.abs(a.sum(0) - b.sum(0)).max() <= 1e-12 * np.abs(b).max() * len(sc)
+    big = rng.standard_normal(20000)                     # n_fft beyond the fused range, not a power of two
+    assert _rel(up.stft(big, np.hanning(5000), n_fft=5000, hop_len=1250), u.stft(big, np.hanning(5000), n_fft=5000, hop_len=1250)) <= 1e-11
