@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 3): the SSQ_CWT_* tuning switches exist only in -DSSQ_TUNING builds: python -m ssqueeze_rs_amd.build --tune, then SSQ_HIP_LIB=$PWD/ssqueeze_rs_amd/libssq_hip_tune.so
 # kernel-time breakdown of the CWT bench for each ablation library: tools/abl_cwt.sh <suffix>...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
