@@ -23,13 +23,14 @@ namespace {
 template <typename T>
 __global__ void istft_expand_kernel(const cpx<T>* __restrict__ Sx, int n, int n_frames, cpx<T>* __restrict__ Z) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = blockIdx.y;
-  if (f >= n_frames || k >= n) return;
-  const int kk = k <= n / 2 ? k : n - k;
-  cpx<T> v = Sx[(long long)kk * n_frames + f];
-  if (k > n / 2) v.y = -v.y;
-  if (k == 0 || (n % 2 == 0 && k == n / 2)) v.y = (T)0;
-  Z[(long long)f * n + k] = v;
+  if (f >= n_frames) return;
+  for (int k = blockIdx.y; k < n; k += gridDim.y) {          // (grid.y is capped at 65535; n_fft may be larger)
+    const int kk = k <= n / 2 ? k : n - k;
+    cpx<T> v = Sx[(long long)kk * n_frames + f];
+    if (k > n / 2) v.y = -v.y;
+    if (k == 0 || (n % 2 == 0 && k == n / 2)) v.y = (T)0;
+    Z[(long long)f * n + k] = v;
+  }
 }
 
 // overlap-add of the windowed frames, window-norm division and unpadding in one gather per output sample
@@ -97,7 +98,8 @@ int istft_typed(const void* Sx, int64_t n_frames, const std::vector<double>& wpo
     if (fail(hipMemcpy(d_S, Sx, sizeof(cpx<T>) * nf * n_frames, hipMemcpyHostToDevice), "hipMemcpy")) break;
     if (fail(hipMemcpy(d_wp, wpow.data(), sizeof(double) * n, hipMemcpyHostToDevice), "hipMemcpy")) break;
     if (fail(hipMemcpy(d_wn, wnorm.data(), sizeof(double) * n, hipMemcpyHostToDevice), "hipMemcpy")) break;
-    hipLaunchKernelGGL(istft_expand_kernel<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)n), dim3(256), 0, nullptr,
+    hipLaunchKernelGGL(istft_expand_kernel<T>, dim3((unsigned)((n_frames + 255) / 256), (unsigned)(n < 65535 ? n : 65535)), dim3(256), 0,
+                       nullptr,
                        d_S, (int)n, (int)n_frames, d_Z);
     if (fail(fft_any_batched<T>(d_Z, d_work, n, n_frames, +1, nullptr), "fft_any_batched")) break;
     hipLaunchKernelGGL(istft_ola_kernel<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, d_Z, (int)n,

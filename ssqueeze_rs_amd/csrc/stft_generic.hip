@@ -18,13 +18,15 @@ template <typename T>
 __global__ void frames_pack_kernel(StftDev<T> p, long long sig, int n_fft, GenericTabs tabs, double alpha,
                                    cpx<T>* __restrict__ Z) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;     // sample inside the frame
-  const int f = blockIdx.y;                                // frame
   if (j >= n_fft) return;
   const T* xs = sig_base(p, sig);
-  const double xv = (double)load_padded(xs, (long long)f * p.hop - p.pad_left + j, p.n_signal, p.padtype);
   int m = j - p.rot;                                       // modulated frames (upstream variant): rotated transform input
   if (m < 0) m += n_fft;
-  Z[(long long)f * n_fft + m] = {(T)(xv * tabs.g[j]), (T)(xv * tabs.gd[j] * alpha)};
+  const double g = tabs.g[j], gd = tabs.gd[j] * alpha;
+  for (int f = blockIdx.y; f < p.n_frames; f += gridDim.y) {   // (grid.y is capped at 65535: hop 1 on a long signal has more frames)
+    const double xv = (double)load_padded(xs, (long long)f * p.hop - p.pad_left + j, p.n_signal, p.padtype);
+    Z[(long long)f * n_fft + m] = {(T)(xv * g), (T)(xv * gd)};
+  }
 }
 
 // Z[frame][k] -> Sx[k][frame] = (Z[k] + conj Z[n-k])/2, dSx[k][frame] = (Z[k] - conj Z[n-k])/(2i) / alpha, through a
@@ -60,7 +62,8 @@ template <typename T>
 hipError_t launch_fft_frames(const StftDev<T>& p, long long sig, int n_fft, const GenericTabs& tabs, double alpha,
                              cpx<T>* Z, cpx<T>* work, cpx<T>* Sx, cpx<T>* dSx, hipStream_t stream) {
   if (p.n_frames > 65535 * 32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(frames_pack_kernel<T>, dim3((n_fft + 255) / 256, p.n_frames), dim3(256), 0, stream, p, sig, n_fft, tabs,
+  hipLaunchKernelGGL(frames_pack_kernel<T>, dim3((n_fft + 255) / 256, p.n_frames < 65535 ? p.n_frames : 65535), dim3(256), 0, stream, p,
+                     sig, n_fft, tabs,
                      dSx ? alpha : 0.0, Z);
   hipError_t e = fft_any_batched<T>(Z, work, n_fft, p.n_frames, -1, stream);
   if (e != hipSuccess) return e;

@@ -284,3 +284,20 @@ def test_edge_shapes():
     assert np.abs(a.sum(0) - b.sum(0)).max() <= 1e-12 * np.abs(b).max() * len(sc)
     big = rng.standard_normal(20000)                     # n_fft beyond the fused range, not a power of two
     assert _rel(up.stft(big, np.hanning(5000), n_fft=5000, hop_len=1250), u.stft(big, np.hanning(5000), n_fft=5000, hop_len=1250)) <= 1e-11
+
+
+def test_hop_one_on_a_long_signal_has_more_frames_than_a_grid_dimension():
+    """upstream's default hop_len is 1: 70 000 frames > 65 535 (the y-limit of a launch grid) through the packing kernel,
+    the inverse, and the n_fft rows of the istft expansion."""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(70000)
+    win = _dpss(32)
+    Sx = up.stft(x, win, n_fft=32, hop_len=1)
+    So = u.stft(x, win, n_fft=32, hop_len=1)
+    assert Sx.shape == (17, 70000) and _rel(Sx, So) <= 1e-11
+    xr = up.istft(Sx, win, n_fft=32, hop_len=1, N=70000)
+    assert np.abs(x - xr).mean() < 1e-14
+    Tx, *_ = up.ssq_stft(x, win, n_fft=32)
+    To, *_ = u.ssq_stft(x, win, n_fft=32)
+    assert np.abs(Tx.sum(0) - To.sum(0)).max() <= 1e-10 * np.abs(To).max() * 17      # invariant under bin flips
+    assert np.abs(up.issq_stft(Tx, win, n_fft=32) - u.issq_stft(To, win, n_fft=32)).max() <= 1e-9
