@@ -91,3 +91,42 @@ def test_admissibility_constants():
     exact = 2 * np.exp(wc ** g - b * np.log(wc)) * G(b / g) / g
     assert abs(u.adm_ssq("gmw") - exact) < 1e-6 * exact
     assert u.p2up(1000) == (2048, 524, 524) and u.p2up(1024) == (2048, 512, 512) and u.p2up(1500)[0] == 4096
+
+
+def test_admissibility_stays_away_from_zero_like_upstream_requires():
+    """old/tests/adm_coef_test.py:16-38: adm_cwt and adm_ssq of the Morlet wavelet exceed 1e-3 for every mu in
+    linspace(4, 30, 200) (an unstable quadrature would give ~0) -- on the restatement AND on the library's host code
+    (`ssq_upstream_adm` needs no GPU)."""
+    import ctypes as C
+    from ssqueeze_rs_amd import _lib
+    lib = _lib.load()
+    out = C.c_double(0)
+    for mu in np.linspace(4, 30, 200)[::10]:
+        w = ("morlet", {"mu": float(mu)})
+        a, b = u.adm_cwt(w), u.adm_ssq(w)
+        assert a > 1e-3 and b > 1e-3
+        for which, ref in ((1, a), (0, b)):
+            assert lib.ssq_upstream_adm(_lib.WAVELET["morlet"], float(mu), 0.0, which, C.byref(out)) == 0
+            assert abs(out.value - ref) <= 1e-10 * ref
+
+
+def test_gmw_bandpass_time_domain_l1_norm_is_two():
+    """old/tests/gmw_test.py:59-81 (norm='bandpass'): the time-domain wavelet built as `compute_gmw(..., time=True)` does
+    (_gmw.py:134-184: positive-frequency half, Nyquist halved, ifft of psih * (-1)^n) has L1 norm 2 to 1e-3, for
+    (gamma, beta) in {(3, 60), (4, 80)}, scales 2 and 3, N = 512 and 513; and the frequency-domain peak is 2."""
+    for g, b in ((3, 60), (4, 80)):
+        for scale in (2, 3):
+            for N in (512, 513):
+                w = u.xifn(scale, N)
+                X = np.zeros(N)
+                X[:N // 2 + 1] = u.gmw_l1(w[:N // 2 + 1], g, b)
+                X[np.isinf(X) | np.isnan(X)] = 0.0
+                Xr = X.copy()
+                if N % 2 == 0:
+                    Xr[N // 2] /= 2
+                psi = np.fft.ifft(Xr * (-1) ** np.arange(N))
+                assert abs(np.sum(np.abs(psi)) - 2) < 1e-3, (g, b, scale, N)
+        wc = (b / g) ** (1 / g)
+        ww = np.linspace(0.5 * wc, 1.5 * wc, 20001)
+        assert abs(u.gmw_l1(ww, g, b).max() - 2) < 1e-6
+        assert abs(u.center_frequency_peak(lambda x: u.gmw_l1(x, g, b), 1.0, 1 << 16) - wc) <= 2 * np.pi / (1 << 16)
