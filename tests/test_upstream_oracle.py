@@ -130,3 +130,18 @@ def test_gmw_bandpass_time_domain_l1_norm_is_two():
         ww = np.linspace(0.5 * wc, 1.5 * wc, 20001)
         assert abs(u.gmw_l1(ww, g, b).max() - 2) < 1e-6
         assert abs(u.center_frequency_peak(lambda x: u.gmw_l1(x, g, b), 1.0, 1 << 16) - wc) <= 2 * np.pi / (1 << 16)
+
+
+def test_modulated_buffer_is_the_ifftshifted_plain_one_exactly():
+    """old/tests/fft_test.py:383-415 (test_buffer): `buffer(..., modulated=True)` equals `ifftshift(buffer(...,
+    modulated=False), axes=0)` with mean absolute difference exactly 0, for even and odd segment lengths and overlaps."""
+    rng = np.random.default_rng(4)
+    N = 128
+    x = rng.standard_normal(N)
+    for seg_len in (N // 2, N // 2 - 1):
+        for n_overlap in (N // 2 - 1, N // 2 - 2, N // 2 - 3):
+            if seg_len == n_overlap:
+                continue
+            a = u.buffer(x, seg_len, n_overlap, True)
+            b = np.fft.ifftshift(u.buffer(x, seg_len, n_overlap, False), axes=0)
+            assert np.abs(a - b).mean() == 0, (seg_len, n_overlap)
