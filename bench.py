@@ -538,6 +538,29 @@ def main():
         sec["c2_one_signal_f32"] = {"ms_per_step": float(np.mean(k1)), "value": one.bins / (float(np.mean(k1)) * 1e-3),
                                     "unit": "TF-bins/s",
                                     "roofline_frac": one.alg_bytes_per_signal / (float(np.mean(k1)) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # the same call captured 20x into one HIP graph (ssq_graph_*): what a launch-bound caller replays per signal
+        try:
+            g, a, b_ = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _lib.check(lib.ssq_graph_capture_begin(stream))
+            for _ in range(20):
+                one.step()
+            _lib.check(lib.ssq_graph_capture_end(stream, C.byref(g)))
+            _lib.check(lib.ssq_event_create(C.byref(a)))
+            _lib.check(lib.ssq_event_create(C.byref(b_)))
+            _lib.check(lib.ssq_graph_launch(g, stream))
+            _lib.check(lib.ssq_event_record(a, stream))
+            for _ in range(5):
+                _lib.check(lib.ssq_graph_launch(g, stream))
+            _lib.check(lib.ssq_event_record(b_, stream))
+            _lib.check(lib.ssq_stream_sync(stream))
+            ms = C.c_float(0)
+            _lib.check(lib.ssq_event_elapsed_ms(a, b_, C.byref(ms)))
+            sec["c2_one_signal_f32"]["ms_per_step_graph_replay"] = ms.value / 100.0
+            for h in (a, b_):
+                lib.ssq_event_destroy(h)
+            lib.ssq_graph_destroy(g)
+        except Exception as e:
+            sec["c2_one_signal_f32"]["graph_replay_error"] = str(e)
         one.close()
         # (2) the reference's own arithmetic: fp64 in, complex128 out, same workload
         l64 = Leg(lib, _lib, np.float64, N, n_fft, hop, B, stream)

@@ -270,6 +270,13 @@ int ssq_event_destroy(void* event);
 int ssq_event_record(void* event, void* stream);
 int ssq_event_sync(void* event);
 int ssq_event_elapsed_ms(void* start, void* stop, float* ms);
+/* HIP graphs: everything the plan execs enqueue on `stream` between begin and end (incl. the ssq_cwt exec's side-stream
+ * fork / join) becomes ONE replayable launch.  Run the sequence once before capturing (lazy one-time setup in the plans);
+ * replay with the same device pointers (new contents).  `stream` must be an explicit stream (ssq_stream_create). */
+int ssq_graph_capture_begin(void* stream);
+int ssq_graph_capture_end(void* stream, void** graph_exec);
+int ssq_graph_launch(void* graph_exec, void* stream);
+int ssq_graph_destroy(void* graph_exec);
 
 #ifdef __cplusplus
 }

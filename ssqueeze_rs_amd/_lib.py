@@ -118,6 +118,10 @@ _SIGNATURES = {
     "ssq_event_record": (C.c_int, [vp, vp]),
     "ssq_event_sync": (C.c_int, [vp]),
     "ssq_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "ssq_graph_capture_begin": (C.c_int, [vp]),
+    "ssq_graph_capture_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "ssq_graph_launch": (C.c_int, [vp, vp]),
+    "ssq_graph_destroy": (C.c_int, [vp]),
 }
 
 

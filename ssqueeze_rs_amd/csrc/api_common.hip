@@ -192,6 +192,40 @@ int ssq_event_elapsed_ms(void* start, void* stop, float* ms) {
   return 0;
 }
 
+
+// ---- HIP graphs: capture a sequence of plan execs on a stream once, replay it with one launch ----------------------
+// The plan execs take device pointers and a stream and neither allocate nor synchronise (the ssq_cwt exec forks its side
+// stream by events, which joins the capture), so a whole per-signal or per-chunk pipeline becomes ONE graph launch: what
+// launch-bound callers want (one 2^20-sample ssq_stft is 17 us of which the kernel is ~7; a chunked multi-channel run is
+// a long chain of small launches).  Run the sequence once before capturing it (lazy one-time setup inside the plans).
+int ssq_graph_capture_begin(void* stream) {
+  if (!stream) SSQ_FAIL("capture needs an explicit stream (not the default stream)");
+  SSQ_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+int ssq_graph_capture_end(void* stream, void** graph_exec) {
+  if (!stream || !graph_exec) SSQ_FAIL("stream or graph_exec is NULL");
+  *graph_exec = nullptr;
+  hipGraph_t g = nullptr;
+  SSQ_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  const hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  SSQ_HIP(e);
+  *graph_exec = ge;
+  return 0;
+}
+int ssq_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) SSQ_FAIL("graph_exec is NULL");
+  SSQ_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return 0;
+}
+int ssq_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return 0;
+  SSQ_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return 0;
+}
+
 }  // extern "C"
 
 extern "C" int ssq_build_has_tuning(void) {
