@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libssq_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
-SOURCES = ["api_common.hip", "api_stft.hip", "stft_fused.hip", "stft_generic.hip",
+SOURCES = ["api_common.hip", "api_stft.hip", "stft_fused.hip", "stft_anylen.hip", "stft_generic.hip",
            "api_cwt.hip", "cwt_kernels.hip", "cwt_reg.hip", "cwt_os.hip", "frontend.hip", "fft_generic.hip", "api_icwt.hip", "host_cache.hip", "api_upstream.hip", "api_gather.hip"]
 CXXFLAGS = ["-std=c++17", "-O3", "-fno-slp-vectorize", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-value"]

@@ -29,6 +29,8 @@ struct ssq_stft_plan {
   bool fft_path = false;           // unfused, but through the batched any-length device FFT instead of direct sums
   int fft_len = 0;                 // length of the fused kernel's transforms: n_fft, or m >= 2*n_fft - 1 in Bluestein mode
   bool blue = false;
+  int mr_np = 0;                   // mixed-radix mode (n_fft = 2^a 3^b 5^c 7^d 11^e 13^f): passes, radices 4 bits each (R - 1)
+  unsigned mr_radix = 0;
   void* d_blue_b = nullptr;        // Bluestein: spectrum of the chirp filter / m
   void* d_blue_post = nullptr;     // Bluestein: output chirp
   int tile_frames = 0;
@@ -47,6 +49,45 @@ struct ssq_stft_plan {
 
 namespace {
 
+// n = 2^a 3^b 5^c 7^d 11^e 13^f -> the pass list of fft_mixed.h: odd radices first (the first pass writes with stride R:
+// an odd stride spreads over the LDS banks, and it needs no twiddles), then 16 / 8 / 4 / 2.  False when n has another
+// prime factor or needs more than 8 passes.
+bool mixed_radix_plan(int n, int& np, unsigned& packed) {
+  std::vector<int> r;
+  int a = 0;
+  while (n % 2 == 0) {
+    n /= 2;
+    ++a;
+  }
+  for (int pr : {13, 11, 7, 5, 3})
+    while (n % pr == 0) {
+      n /= pr;
+      r.push_back(pr);
+    }
+  if (n != 1) {
+    np = 0;
+    return false;
+  }
+  while (a >= 4 && a != 5) {
+    r.push_back(16);
+    a -= 4;
+  }
+  while (a >= 3) {
+    r.push_back(8);
+    a -= 3;
+  }
+  if (a == 2) r.push_back(4);
+  if (a == 1) r.push_back(2);
+  if (r.size() > 8) {
+    np = 0;
+    return false;
+  }
+  np = (int)r.size();
+  packed = 0;
+  for (size_t i = 0; i < r.size(); ++i) packed |= (unsigned)(r[i] - 1) << (4 * i);
+  return true;
+}
+
 template <typename T>
 int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::vector<double>& gdfs) {
   const int n = pl->n_fft;
@@ -59,8 +100,9 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
     twre[i] = (double)cosl(ang);
     twim[i] = (double)(-sinl(ang));
   }
+  const int tw_n = pl->mr_np > 0 ? n : m;                      // mixed-radix mode: the W_n table itself
   for (int i = 0; i < m; ++i) {
-    const long double ang = 2.0L * PI * (long double)i / (long double)m;
+    const long double ang = 2.0L * PI * (long double)(i % tw_n) / (long double)tw_n;
     tw[i] = {(T)cosl(ang), (T)(-sinl(ang))};
   }
   std::vector<host::cd> chirp((size_t)n);                      // exp(-i*pi*j^2/n), j^2 reduced mod 2n
@@ -149,9 +191,11 @@ StftDev<T> make_dev(const ssq_stft_plan* pl, int out_kind, const void* d_x, void
   p.inv_alpha = (T)(1.0 / pl->alpha);
   p.two_pi_eff = (T)(6.283185307179586 * (pl->fused ? pl->alpha : 1.0));
   p.leb_unit = (T)(1.0 / (double)pl->n_freqs);
-  p.n_eff = pl->fused ? (pl->blue ? pl->n_fft : pl->fft_len) : pl->n_fft;
+  p.n_eff = pl->fused ? ((pl->blue || pl->mr_np > 0) ? pl->n_fft : pl->fft_len) : pl->n_fft;
   p.blue_b = (const cpx<T>*)pl->d_blue_b;
   p.blue_post = (const cpx<T>*)pl->d_blue_post;
+  p.mr_np = pl->mr_np;
+  p.mr_radix = pl->mr_radix;
   {
     // keep  <=>  den >= g2 (fp32 values).  With BIG = 1/ulp(g2): (den - g2)*BIG is 0 at equality and <= -1 for every
     // representable den < g2, so clamp(den*BIG + (1 - g2*BIG)) is exactly the 0/1 mask (g2*BIG is an integer < 2^24).
@@ -303,9 +347,18 @@ int ssq_stft_plan_create_v(ssq_stft_plan** plan, int dtype, int64_t n_signal, co
   const bool f32 = dtype == SSQ_F32;
   pl->fft_len = (int)n_fft;
   pl->fused = !force_generic && (f32 ? fused_supported<float>((int)n_fft) : fused_supported<double>((int)n_fft));
-  if (!pl->fused && !force_generic && !host::is_pow2(n_fft) && n_fft >= 24 && n_fft <= 2048) {
-    // rustfft plans any length (stft.rs:43-44): lengths that are not a power of two run Bluestein's chirp-z inside the
-    // fused kernel, through two of its power-of-two transforms of length m >= 2*n_fft - 1 (m <= 4096)
+  if (!pl->fused && !force_generic && !host::is_pow2(n_fft) && n_fft >= 24 && n_fft <= 4096 &&
+      mixed_radix_plan((int)n_fft, pl->mr_np, pl->mr_radix)) {
+    // rustfft plans any length (stft.rs:43-44): lengths with prime factors <= 13 run mixed-radix passes inside the fused
+    // kernel of the next power of two (fft_mixed.h) ...
+    int m = 64;
+    while (m < (int)n_fft) m <<= 1;
+    pl->fft_len = m;
+    pl->fused = true;
+  } else if (!pl->fused && !force_generic && !host::is_pow2(n_fft) && n_fft >= 24 && n_fft <= 2048) {
+    // ... and the others Bluestein's chirp-z, through two of its power-of-two transforms of length
+    // m >= 2*n_fft - 1 (m <= 4096)
+    pl->mr_np = 0;
     int m = 64;
     while (m < 2 * (int)n_fft - 1) m <<= 1;
     pl->fft_len = m;

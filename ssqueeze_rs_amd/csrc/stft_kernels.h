@@ -54,6 +54,11 @@ struct StftDev {
   int n_eff;               // n_fft actually transformed (== 2^LOGN outside Bluestein mode)
   const cpx<T>* blue_b;
   const cpx<T>* blue_post;
+  // Mixed-radix mode of the fused kernel (n_fft = 2^a 3^b 5^c 7^d 11^e 13^f, not a power of two): mr_np > 0 passes
+  // inside the frame's exchange row (fft_mixed.h), radix of pass i = 1 + ((mr_radix >> 4i) & 15); tw is then the
+  // W_{n_eff} table, win2 the plain window tables zero-padded to 2^LOGN.
+  int mr_np;
+  unsigned mr_radix;
 };
 
 template <typename T>
@@ -71,6 +76,9 @@ int fused_tile_frames(int n_fft);          // frames per output tile (F)
 // launches the interior-tile kernel (direct loads) and the edge-tile kernel (mirrored/zero padding)
 template <typename T>
 hipError_t launch_stft_fused(const StftDev<T>& p, int n_fft, int cu_count, long long batch, hipStream_t stream);
+// the any-length modes of the same kernel (stft_anylen.hip): p.n_eff != fft_len
+template <typename T>
+hipError_t launch_stft_anylen(const StftDev<T>& p, int fft_len, int cu_count, long long batch, hipStream_t stream);
 
 // generic any-n_fft kernels (stft_generic.hip); tables are always double
 struct GenericTabs {
@@ -192,6 +200,18 @@ __device__ __forceinline__ T load_padded(const T* __restrict__ xs, long long m, 
   long long mm = (m < 0) ? -m : (2 * n - 2 - m);
   if (mm >= 0 && mm < n) return xs[mm];
   return (T)0;
+}
+
+// The same fetch without branches (index selects, one unconditional load): a loader that takes it for many samples in
+// a row keeps all its loads in flight (the branchy form waits for each load at the join).  `live` = false returns 0.
+template <typename T>
+__device__ __forceinline__ T load_padded_flat(const T* __restrict__ xs, long long m, long long n, int padtype, bool live) {
+  const bool in = m >= 0 && m < n;
+  const long long mm = (m < 0) ? -m : (2 * n - 2 - m);
+  const bool ok = live && (in || (padtype == 0 && mm >= 0 && mm < n));
+  const long long idx = in ? m : mm;
+  const T v = xs[ok ? idx : 0];
+  return ok ? v : (T)0;
 }
 
 }  // namespace ssq

@@ -301,13 +301,16 @@ def test_error_behaviour_matches_reference():
     assert _rs.hello_from_bin() == "Hello from ssqueeze!"
 
 
-# ------------------------------------------------------- any-length n_fft: Bluestein inside the fused kernel ----
+# ------------------------- any-length n_fft inside the fused kernel: mixed-radix passes (prime factors <= 13) or Bluestein ----
 @pytest.mark.parametrize("n_fft,hop", [(1000, 250), (999, 100), (1001, 333), (100, 25), (24, 6), (33, 8), (600, 150),
-                                       (1025, 256), (2047, 512), (1536, 384)])
+                                       (1025, 256), (2047, 512), (1536, 384), (2187, 500), (4095, 1024), (3000, 750),
+                                       (77, 20), (1920, 480), (96, 24), (2002, 500), (4000, 1000), (26, 5), (1014, 250),
+                                       (968, 242), (130, 32), (2058, 512)])
 @pytest.mark.parametrize("dtype,tol", [(np.float64, 1e-11), (np.float32, 6e-6)])
 def test_stft_bluestein_lengths(n_fft, hop, dtype, tol):
-    """rustfft plans any length (stft.rs:43-44, ssq_stft.rs:198-199); 24 <= n_fft <= 2048 that are not powers of two
-    run Bluestein's chirp-z through two power-of-two transforms of the fused kernel (no O(n^2) direct sums)."""
+    """rustfft plans any length (stft.rs:43-44, ssq_stft.rs:198-199); 24 <= n_fft <= 4096 with prime factors <= 13 run
+    mixed-radix passes (fft_mixed.h: every radix 2..16 of its list is met here), other n_fft <= 2048 Bluestein's chirp-z
+    through two power-of-two transforms, all inside the fused kernel (no O(n^2) direct sums)."""
     import ctypes as C
     from ssqueeze_rs_amd import _lib
     x = _sig(5 * n_fft + 123, 21, dtype)
@@ -326,7 +329,7 @@ def test_stft_bluestein_lengths(n_fft, hop, dtype, tol):
         assert _relerr(Sx, Sx_o) <= tol, (n_fft, pad)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (333, 83), (48, 12)])
+@pytest.mark.parametrize("n_fft,hop", [(1000, 250), (333, 83), (48, 12), (1536, 384), (3000, 750), (231, 50)])
 def test_ssq_stft_bluestein(n_fft, hop):
     x = _sig(6000 + 3 * n_fft, 22)
     _check_ssq_f64(x, np.hanning(n_fft), n_fft, hop, 2.0, "reflect", "sum")
