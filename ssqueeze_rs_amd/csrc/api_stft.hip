@@ -49,35 +49,37 @@ struct ssq_stft_plan {
 
 namespace {
 
-// n = 2^a 3^b 5^c 7^d 11^e 13^f -> the pass list of fft_mixed.h: odd radices first (the first pass writes with stride R:
-// an odd stride spreads over the LDS banks, and it needs no twiddles), then 16 / 8 / 4 / 2.  False when n has another
-// prime factor or needs more than 8 passes.
+// n = 2^a 3^b 5^c 7^d 11^e 13^f -> the pass list of fft_mixed.h.  Fewest passes first (every pass is one LDS round trip
+// of the frame): 2s and 3s pair with 5s and 3s into the twiddle-free radices 10, 15, 12, 6, the other 2s group into
+// 16 / 8 / 4 / 2; odd radices go first (the first pass writes with stride R: an odd stride spreads over the LDS banks).
+// False when n has another prime factor or needs more than 8 passes.
 bool mixed_radix_plan(int n, int& np, unsigned& packed) {
-  std::vector<int> r;
-  int a = 0;
-  while (n % 2 == 0) {
-    n /= 2;
-    ++a;
-  }
-  for (int pr : {13, 11, 7, 5, 3})
+  int e2 = 0, e3 = 0, e5 = 0;
+  std::vector<int> odd, even;
+  while (n % 2 == 0) n /= 2, ++e2;
+  while (n % 3 == 0) n /= 3, ++e3;
+  while (n % 5 == 0) n /= 5, ++e5;
+  for (int pr : {13, 11, 7})
     while (n % pr == 0) {
       n /= pr;
-      r.push_back(pr);
+      odd.push_back(pr);
     }
   if (n != 1) {
     np = 0;
     return false;
   }
-  while (a >= 4 && a != 5) {
-    r.push_back(16);
-    a -= 4;
-  }
-  while (a >= 3) {
-    r.push_back(8);
-    a -= 3;
-  }
-  if (a == 2) r.push_back(4);
-  if (a == 1) r.push_back(2);
+  while (e5 > 0 && e2 > 0) even.push_back(10), --e5, --e2;
+  while (e5 > 0 && e3 > 0) odd.push_back(15), --e5, --e3;
+  while (e3 > 0 && e2 >= 2) even.push_back(12), --e3, e2 -= 2;
+  while (e3 > 0 && e2 >= 1) even.push_back(6), --e3, --e2;
+  while (e5 > 0) odd.push_back(5), --e5;
+  while (e3 > 0) odd.push_back(3), --e3;
+  while (e2 >= 4 && e2 != 5) even.push_back(16), e2 -= 4;
+  while (e2 >= 3) even.push_back(8), e2 -= 3;
+  if (e2 == 2) even.push_back(4);
+  if (e2 == 1) even.push_back(2);
+  std::vector<int> r(odd);
+  r.insert(r.end(), even.begin(), even.end());
   if (r.size() > 8) {
     np = 0;
     return false;

@@ -1,6 +1,7 @@
 // fft_mixed.h -- mixed-radix Stockham transform of one frame inside its LDS exchange row (gfx950).
 //
-// rustfft plans any length (stft.rs:43-44); lengths n = 2^a 3^b 5^c 7^d 11^e 13^f run here, inside the fused STFT kernel,
+// rustfft plans any length (stft.rs:43-44); lengths n = 2^a 3^b 5^c 7^d 11^e 13^f run here, inside the fused STFT kernel
+// (radices 2..16: the primes, 4 / 8 / 16, and 6 / 10 / 12 / 15 as twiddle-free Good-Thomas pairs),
 // instead of through Bluestein's two power-of-two transforms of >= 2n - 1 points.  The frame's L lanes walk the passes of
 // the host's radix list: a pass of radix R has n/R butterflies, lane t takes butterflies t, t + L, ...; all inputs of a
 // lane are read before any output is written (the transform is in place in the row), outputs land at their autosort
@@ -83,12 +84,58 @@ __device__ __forceinline__ void dft_odd(cpx<T> (&a)[R]) {
 }
 
 template <typename T, int R>
+__device__ __forceinline__ void dft_any(cpx<T> (&a)[R]);
+
+constexpr int mod_inverse(int a, int m) {            // a^-1 mod m, gcd(a, m) = 1
+  for (int x = 1; x < m; ++x)
+    if ((a * x) % m == 1) return x;
+  return 1;
+}
+
+// Good-Thomas: R = N1 * N2 with gcd(N1, N2) = 1 needs no twiddles between its two stages.
+//   n = (N2 n1 + N1 n2) mod R,   k = (k1 N2 (N2^-1 mod N1) + k2 N1 (N1^-1 mod N2)) mod R
+template <typename T, int N1, int N2>
+__device__ __forceinline__ void dft_pfa(cpx<T> (&a)[N1 * N2]) {
+  constexpr int R = N1 * N2;
+  constexpr int E1 = N2 * mod_inverse(N2 % N1, N1), E2 = N1 * mod_inverse(N1 % N2, N2);
+  cpx<T> b[N2][N1];
+#pragma unroll
+  for (int n2 = 0; n2 < N2; ++n2) {
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) b[n2][n1] = a[(N2 * n1 + N1 * n2) % R];
+    dft_any<T, N1>(b[n2]);
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < N1; ++k1) {
+    cpx<T> c[N2];
+#pragma unroll
+    for (int n2 = 0; n2 < N2; ++n2) c[n2] = b[n2][k1];
+    dft_any<T, N2>(c);
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) a[(k1 * E1 + k2 * E2) % R] = c[k2];
+  }
+}
+
+template <typename T, int R>
 __device__ __forceinline__ void dft_any(cpx<T> (&a)[R]) {
   if constexpr (R == 2) dft2<false>(a[0], a[1]);
   else if constexpr (R == 4) dft4<false>(a[0], a[1], a[2], a[3]);
   else if constexpr (R == 8) dft8<false>(a);
   else if constexpr (R == 16) dft16<false>(a);
+  else if constexpr (R == 6) dft_pfa<T, 2, 3>(a);
+  else if constexpr (R == 10) dft_pfa<T, 2, 5>(a);
+  else if constexpr (R == 12) dft_pfa<T, 4, 3>(a);
+  else if constexpr (R == 15) dft_pfa<T, 3, 5>(a);
   else dft_odd<T, R>(a);
+}
+
+// Ordering point between a pass's reads and its writes (and the next pass's reads).  A frame inside one wave needs no
+// wait: the LDS unit runs a wave's DS operations in issue order, so only the compiler must keep the order (aliasing
+// accesses to the same row: it does; the barrier pins the schedule).  A multi-wave frame needs the block barrier.
+template <bool MULTIWAVE>
+__device__ __forceinline__ void row_order() {
+  if constexpr (MULTIWAVE) __syncthreads();
+  else __builtin_amdgcn_wave_barrier();
 }
 
 // One pass: radix R, Ns = product of the radices of the earlier passes, rem = n / (Ns * R).
@@ -106,7 +153,7 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* row, int n, int Ns, int rem, 
       for (int u = 0; u < R; ++u) a[r][u] = row[exch_phys(j + u * nb)];
     }
   }
-  frame_sync<MULTIWAVE>();
+  row_order<MULTIWAVE>();
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int j = t + L * r;
@@ -125,7 +172,7 @@ __device__ __forceinline__ void mixed_pass(cpx<T>* row, int n, int Ns, int rem, 
       for (int u = 0; u < R; ++u) row[exch_phys(base + u * Ns)] = a[r][u];
     }
   }
-  frame_sync<MULTIWAVE>();
+  row_order<MULTIWAVE>();
 }
 
 // All passes of the host's plan (np radices, 4 bits each: R - 1; every lane of the block sees the same list, so the barriers inside a
@@ -145,6 +192,10 @@ __device__ __forceinline__ void fft_mixed_row(cpx<T>* row, int n, int np, unsign
       case 5: mixed_pass<T, L, 5, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
       case 7: mixed_pass<T, L, 7, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
       case 8: mixed_pass<T, L, 8, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
+      case 6: mixed_pass<T, L, 6, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
+      case 10: mixed_pass<T, L, 10, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
+      case 12: mixed_pass<T, L, 12, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
+      case 15: mixed_pass<T, L, 15, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
       case 11: mixed_pass<T, L, 11, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
       case 13: mixed_pass<T, L, 13, MULTIWAVE>(row, n, Ns, rem, tw, t); break;
       default: mixed_pass<T, L, 16, MULTIWAVE>(row, n, Ns, rem, tw, t); break;

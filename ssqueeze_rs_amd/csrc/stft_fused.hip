@@ -142,9 +142,16 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 #pragma unroll
       for (int q = 0; q < 16; ++q) xv[q] = xs[pos0 + L * q];
     } else {
+      // one wave-uniform branch around two straight runs of loads (a branch per sample makes every load wait for itself)
       const bool valid = frame < p.n_frames;
+      const long long first = pos0 - t;
+      if (__all(valid && first >= 0 && first + N <= p.n_signal)) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) xv[q] = valid ? load_padded(xs, pos0 + L * q, p.n_signal, p.padtype) : 0.0f;
+        for (int q = 0; q < 16; ++q) xv[q] = xs[pos0 + L * q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xv[q] = load_padded_flat(xs, pos0 + L * q, p.n_signal, p.padtype, valid);
+      }
     }
   };
   T xn[16];

@@ -255,9 +255,14 @@ __device__ __forceinline__ void load_samples(const StftDev<T>& p, const TileItem
 #pragma unroll
     for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
   } else {
+    const long long first = w.pos0 - t;
+    if (__all(w.valid && first >= 0 && first + FusedCfg<T, LOGN>::N <= p.n_signal)) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
-      xv[q] = w.valid ? load_padded(w.xs, w.pos0 + L * q, p.n_signal, p.padtype) : (T)0;
+      for (int q = 0; q < 16; ++q) xv[q] = w.xs[w.pos0 + L * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xv[q] = load_padded_flat(w.xs, w.pos0 + L * q, p.n_signal, p.padtype, w.valid != 0);
+    }
   }
 }
 
