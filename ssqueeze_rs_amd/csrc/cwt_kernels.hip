@@ -192,7 +192,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
   auto fetch = [&](int e) -> cpx<T> {
     if constexpr (MODE == CWT_FWD_A) {
       const long long n = (long long)(e / C) * P2 + t0 + (e % C);
-      return {load_padded(p.x, n - p.n1, p.n_signal, p.padtype), (T)0};
+      return {load_padded_flat(p.x, n - p.n1, p.n_signal, p.padtype, true), (T)0};   // (no branch: the batch stays in flight)
     } else if constexpr (MODE == CWT_INV_A) {
       const long long n = (long long)(e / C) * P2 + t0 + (e % C);
       return conj_if(load_spectrum(p, tr, n), true);
@@ -215,7 +215,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
       const int m = e % M;
       const long long trc = t0 + e / M;
       if (trc >= p.n_transforms) return {(T)0, (T)0};
-      if constexpr (MODE == CWT_FWD_S) return {load_padded(p.x, (long long)m - p.n1, p.n_signal, p.padtype), (T)0};
+      if constexpr (MODE == CWT_FWD_S) return {load_padded_flat(p.x, (long long)m - p.n1, p.n_signal, p.padtype, true), (T)0};
       else return conj_if(load_spectrum(p, (int)trc, m), true);
     }
   };
