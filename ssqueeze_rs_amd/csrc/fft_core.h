@@ -91,6 +91,51 @@ __device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cp
   }
 }
 
+// The same transform for a frame inside ONE wave with an exchange row of T instead of cpx<T>: the real parts go through
+// the row, then the imaginary parts (fp64: twice the DS instructions of half the width -- the same bytes -- for half the
+// LDS footprint, which is what lets eight fp64 frames share a CU).
+template <typename T, int LOGN, int P>
+__device__ __forceinline__ void fft_exchange_split(cpx<T> (&v)[16], T* exch, int t) {
+  constexpr int N = 1 << LOGN, L = N / 16;
+  static_assert(L <= 64, "single-wave frames");
+  constexpr int R = pass_radix(LOGN, P), NS = pass_ns(LOGN, P), NB = 16 / R;
+  T nx[16];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = t + L * b;
+    const int k = j & (NS - 1);
+    const int base = (j - k) * R + k;
+#pragma unroll
+    for (int u = 0; u < R; ++u) exch[exch_phys(base + u * NS)] = v[b + u * NB].x;
+  }
+  frame_sync<false>();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) nx[q] = exch[exch_phys(t + L * q)];
+  frame_sync<false>();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = t + L * b;
+    const int k = j & (NS - 1);
+    const int base = (j - k) * R + k;
+#pragma unroll
+    for (int u = 0; u < R; ++u) exch[exch_phys(base + u * NS)] = v[b + u * NB].y;
+  }
+  frame_sync<false>();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = {nx[q], exch[exch_phys(t + L * q)]};
+  frame_sync<false>();
+}
+
+template <typename T, int LOGN, int P>
+__device__ __forceinline__ void fft_pass_split(cpx<T> (&v)[16], T* exch, const cpx<T> (&twr)[3][16],
+                                               const cpx<T>* __restrict__ tw_tab, int t) {
+  fft_compute<T, LOGN, P, false, false>(v, twr, tw_tab, t);
+  if constexpr (P < num_passes(LOGN) - 1) {
+    fft_exchange_split<T, LOGN, P>(v, exch, t);
+    fft_pass_split<T, LOGN, P + 1>(v, exch, twr, tw_tab, t);
+  }
+}
+
 // Two frames of one wave, staggered: while one frame's exchange is in flight the other computes.
 template <typename T, int LOGN, int P, bool INV, bool TW_REGS>
 __device__ __forceinline__ void fft_pass_pair(cpx<T> (&a)[16], cpx<T> (&b)[16], cpx<T>* exch,

@@ -10,7 +10,7 @@ namespace ssq {
 
 template <typename T, int LOGN>
 static hipError_t launch_anylen_one(const StftDev<T>& p0, int cu_count, long long batch, hipStream_t stream) {
-  using C = FusedCfg<T, LOGN>;
+  using C = FusedCfg<T, LOGN, true>;
   int per_cu = (160 * 1024) / C::LDS_BYTES;
   if (per_cu < 1) per_cu = 1;
   if (per_cu * C::W > 32) per_cu = 32 / C::W;

@@ -24,7 +24,7 @@
 // (187 cycles per wave instruction, measured: tools/ubench/lds_atomics.hip) while integer LDS
 // atomics run at ~4 cycles per wave instruction.  Each column (frame) gets its own power-of-two
 // scale 2^(FRAC-e) with 2^e > the column's L1 mass, so no partial sum can overflow, the
-// quantisation step (2^-30 resp. 2^-62 of the column's L1 mass) sits below the FFT's own
+// quantisation step (2^-30 resp. 2^-50 of the column's L1 mass) sits below the FFT's own
 // rounding error, and -- integer adds being associative -- the result is bitwise reproducible.
 //
 // The window tables arrive pre-multiplied by 1/2 (so the unpack needs no scaling) and the
@@ -40,20 +40,34 @@
 
 namespace ssq {
 
-template <typename T, int LOGN>
+#ifndef SSQ_F64_MAGIC
+#define SSQ_F64_MAGIC 1     // fp64 fixed point by the 1.5 * 2^52 rounding trick (50 fraction bits) instead of f64 -> i64 conversions (62)
+#endif
+
+#ifndef SSQ_F64_W8
+#define SSQ_F64_W8 1        // fp64 n_fft = 1024 with EIGHT waves per block (two per SIMD): exchange rows of T (re, then im), one-deep
+                            // prefetch, weights parked in the row, window table in LDS: 1.95 -> 1.61 ms at batch 64 (r03_ab_f64_w8.txt)
+#endif
+
+// ANY: the any-length modes of the kernel (stft_anylen.hip) keep the plain configuration (their transforms use the
+// exchange row as a row of complex values)
+template <typename T, int LOGN, bool ANY = false>
 struct FusedCfg {
   static constexpr int N = 1 << LOGN;
   static constexpr int L = N / 16;                         // lanes per frame
-  static constexpr int W = (sizeof(T) == 4) ? 8 : 4;       // waves per block
+  static constexpr bool SPLIT = SSQ_F64_W8 && sizeof(T) == 8 && LOGN == 10 && !ANY;   // exchange the components one after the other
+  static constexpr int W = (sizeof(T) == 4 || SPLIT) ? 8 : 4;   // waves per block
   static constexpr int FPW = (L >= 64) ? 1 : 64 / L;       // frames per wave
   static constexpr int WPF = (L <= 64) ? 1 : L / 64;       // waves per frame
   static constexpr int FIF = W * FPW / WPF;                // frames in flight per block
   static constexpr int NF = N / 2 + 1;
   static constexpr int EXCH_ELEMS = N + N / 16;            // +1 element per 16: bank spread
-  static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)sizeof(cpx<T>);
-  static constexpr bool WIN_LDS = (sizeof(T) == 4) && (N <= 1024);   // window table in LDS
+  static constexpr int EXCH_BYTES = FIF * EXCH_ELEMS * (int)(SPLIT ? sizeof(T) : sizeof(cpx<T>));
+  // window table in LDS (SPLIT: -14 %; the W_1024 table there instead, random-index reads, measured 5 % slower than
+  // leaving it to L1: profiles/r03_ab_f64_w8.txt)
+  static constexpr bool WIN_LDS = ((sizeof(T) == 4) && (N <= 1024)) || SPLIT;
   static constexpr int WIN_BYTES = WIN_LDS ? N * (int)sizeof(cpx<T>) : 0;
-  static constexpr int TWL_BYTES = WIN_LDS ? N * (int)sizeof(cpx<T>) : 0;   // W_N table in LDS (paired-frame kernels)
+  static constexpr int TWL_BYTES = (WIN_LDS && !SPLIT) ? N * (int)sizeof(cpx<T>) : 0;   // W_N table in LDS (paired-frame / mixed-radix kernels)
   static constexpr int LDS_MAX = 160 * 1024;
   static constexpr int FMAX = (LDS_MAX - EXCH_BYTES - WIN_BYTES - TWL_BYTES - 1024) / (2 * NF * (int)sizeof(T)) - 1;
   static constexpr int FT = (sizeof(T) == 4) ? 16 : 8;     // target: >=128-B row segments
@@ -64,7 +78,7 @@ struct FusedCfg {
   static constexpr int TILE_BYTES = (((2 * PLANE + F) * (int)sizeof(T) + 15) / 16) * 16;   // + col_scale[F]
   using IT = std::conditional_t<sizeof(T) == 4, int, long long>;
   using UT = std::conditional_t<sizeof(T) == 4, unsigned int, unsigned long long>;
-  static constexpr int FRAC = (sizeof(T) == 4) ? 30 : 62;      // fixed-point fraction bits
+  static constexpr int FRAC = (sizeof(T) == 4) ? 30 : (SSQ_F64_MAGIC ? 50 : 62);      // fixed-point fraction bits (fp64: below 2^51, to_fixed)
   static constexpr int EMIN = (sizeof(T) == 4) ? -90 : -960;   // keeps 2^(FRAC-e) finite
   static constexpr int LDS_BYTES = TILE_BYTES + EXCH_BYTES + WIN_BYTES + TWL_BYTES;
   static constexpr int NP = num_passes(LOGN);
@@ -90,7 +104,22 @@ __device__ __forceinline__ T from_int(std::conditional_t<sizeof(T) == 4, int, lo
 template <typename T>
 __device__ __forceinline__ std::conditional_t<sizeof(T) == 4, int, long long> to_fixed(T v) {
   if constexpr (sizeof(T) == 4) return cvt_round_i32(v);      // floor(v + 1/2): one instruction
-  else return __double2ll_rn(v);
+  else if constexpr (!SSQ_F64_MAGIC) return __double2ll_rn(v);
+  else {
+    // |v| <= 2^50 (FRAC): adding 1.5 * 2^52 leaves round-to-nearest-even(v) in the low mantissa bits -- one fp64 add and
+    // one 64-bit subtract instead of the ~18-instruction f64 -> i64 conversion (there is no native one)
+    constexpr double kMagic = 6755399441055744.0;
+    return __double_as_longlong(v + kMagic) - __double_as_longlong(kMagic);
+  }
+}
+// the way back for |i| < 2^51: exact
+template <typename T>
+__device__ __forceinline__ T fixed_to_real(std::conditional_t<sizeof(T) == 4, int, long long> i) {
+  if constexpr (sizeof(T) == 4 || !SSQ_F64_MAGIC) return (T)i;
+  else {
+    constexpr double kMagic = 6755399441055744.0;
+    return __longlong_as_double(i + __double_as_longlong(kMagic)) - kMagic;
+  }
 }
 
 template <int CTRL>
@@ -206,9 +235,9 @@ __device__ __forceinline__ TileItem make_tile(const StftDev<T>& p, long long sig
   return w;
 }
 
-template <typename T, int LOGN, bool EDGE>
+template <typename T, int LOGN, bool EDGE, bool ANY = false>
 __device__ __forceinline__ FrameItem<T> make_frame(const StftDev<T>& p, const TileItem& tl, int it, int slot, int t) {
-  using C = FusedCfg<T, LOGN>;
+  using C = FusedCfg<T, LOGN, ANY>;
   FrameItem<T> w;
   w.fl = it * C::FIF + slot;
   const int frame = tl.frame0 + w.fl;
@@ -313,8 +342,8 @@ __device__ __forceinline__ unsigned long long ssq_stamp() {
 // MODE: 0 = power-of-two n_fft; 1 = BLUE; 2 = MIXR, any n_fft = p.n_eff <= 2^LOGN whose prime factors are <= 13: the
 // frame is transformed in its exchange row by the mixed-radix passes of fft_mixed.h (p.mr_radix), same epilogue as BLUE.
 template <typename T, int LOGN, bool TXONLY, bool EDGE, bool LEB, bool WKDBG = false, int MODE = 0>
-__global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
-  using C = FusedCfg<T, LOGN>;
+__global__ __launch_bounds__((FusedCfg<T, LOGN, MODE != 0>::W * 64)) void stft_fused_kernel(StftDev<T> p) {
+  using C = FusedCfg<T, LOGN, MODE != 0>;
   constexpr int N = C::N, L = C::L, NF = C::NF, F = C::F, PITCH = C::PITCH;
   constexpr bool MULTIWAVE = (C::WPF > 1);
   constexpr bool BLUE = MODE == 1, MIXR = MODE == 2, ANYLEN = MODE != 0;
@@ -345,7 +374,8 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
     slot = wave / C::WPF;
     t = (wave % C::WPF) * 64 + lane;
   }
-  cpx<T>* exch = exch_all + slot * C::EXCH_ELEMS;
+  cpx<T>* exch = exch_all + (C::SPLIT ? 0 : slot * C::EXCH_ELEMS);
+  T* exch_s = reinterpret_cast<T*>(exch_all) + slot * C::EXCH_ELEMS;       // SPLIT: a row of T per frame
 
   // ---- per-lane constants, live across all tiles this block processes ----
   constexpr bool TW_REGS = C::TW_REGS && !PAIR && !MIXR;   // paired frames: registers go to the second frame, twiddles to LDS
@@ -369,7 +399,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   if constexpr (C::WIN_LDS) {
     for (int i = tid; i < N; i += C::W * 64) win_lds[i] = p.win2[i];
   }
-  constexpr bool TW_LDS = PAIR || (MIXR && C::WIN_LDS);      // W_n table in LDS (the area exists with WIN_LDS)
+  constexpr bool TW_LDS = PAIR || (MIXR && C::WIN_LDS && !C::SPLIT);      // W_n table in LDS (the area exists with WIN_LDS)
   if constexpr (TW_LDS) {
     for (int i = tid; i < N; i += C::W * 64) tw_lds[i] = p.tw[i];
   }
@@ -410,15 +440,16 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   i0.ok = 1;
   Item i1 = advance(i0);
   static_assert(NFW == 1, "frame pairing is parked (see PAIR)");
+  constexpr bool DEEP = !C::SPLIT;     // SPLIT: one item ahead (registers; two waves per SIMD hide the rest)
   FrameItem<T> cur[NFW];
   T xn[NFW][16];      // samples of the current item
-  T xb[16];           // samples of the next item
-  cur[0] = make_frame<T, LOGN, EDGE>(p, i0.tl, i0.ig, slot, t);
+  T xb[DEEP ? 16 : 1];           // samples of the next item
+  cur[0] = make_frame<T, LOGN, EDGE, MODE != 0>(p, i0.tl, i0.ig, slot, t);
   load_samples<T, LOGN, EDGE, MODE>(p, i0.tl, cur[0], xn[0], t);
   FrameItem<T> fr1 = cur[0];
   if (i1.ok) {
-    fr1 = make_frame<T, LOGN, EDGE>(p, i1.tl, i1.ig, slot, t);
-    load_samples<T, LOGN, EDGE, MODE>(p, i1.tl, fr1, xb, t);
+    fr1 = make_frame<T, LOGN, EDGE, MODE != 0>(p, i1.tl, i1.ig, slot, t);
+    if constexpr (DEEP) load_samples<T, LOGN, EDGE, MODE>(p, i1.tl, fr1, xb, t);
   }
 #ifdef SSQ_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -429,24 +460,43 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
   while (true) {
     const TileItem tl = i0.tl;
     const int ig = i0.ig;
+    // SPLIT: the window and twiddle tables are read from memory (L1) in EVERY iteration -- the loads are loop
+    // invariant, and hoisted out of the loop they would hold (and spill) ~180 registers; an opaque zero offset per
+    // iteration keeps them where they are used
+    const cpx<T>* win_it = p.win2;
+    const cpx<T>* tw_it = tw_src;
+    if constexpr (C::SPLIT) {
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      win_it += z;
+      tw_it += z;
+    }
     // ---- window multiply ----
     cpx<T> v[NFW][16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : p.win2[t + L * q];
+      const cpx<T> wq = C::WIN_LDS ? win_lds[t + L * q] : win_it[t + L * q];
       v[0][q] = {xn[0][q] * wq.x, xn[0][q] * wq.y};
     }
     SSQ_STAMP(0);
     const bool has_next = i1.ok;
     // rotate the prefetch ring: the next item's samples (loaded one iteration ago) move to xn and the
     // loads of the item after next go out now, a full iteration before they are needed
+    if constexpr (DEEP) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) xn[0][q] = xb[q];
+      for (int q = 0; q < 16; ++q) xn[0][q] = xb[q];
+    } else {
+      // (issued behind the transform instead -- so that its twiddle loads do not queue behind these -- measured 3 %
+      //  slower: the epilogue alone does not cover the latency before the tile barrier drains the loads)
+      if (i1.ok) load_samples<T, LOGN, EDGE, MODE>(p, i1.tl, fr1, xn[0], t);
+    }
     const Item i2 = advance(i1);
     FrameItem<T> fr2 = fr1;
     if (i2.ok) {
-      fr2 = make_frame<T, LOGN, EDGE>(p, i2.tl, i2.ig, slot, t);
-      if (!SSQ_ABL(1)) load_samples<T, LOGN, EDGE, MODE>(p, i2.tl, fr2, xb, t);
+      fr2 = make_frame<T, LOGN, EDGE, MODE != 0>(p, i2.tl, i2.ig, slot, t);
+      if constexpr (DEEP) {
+        if (!SSQ_ABL(1)) load_samples<T, LOGN, EDGE, MODE>(p, i2.tl, fr2, xb, t);
+      }
     }
 
     SSQ_STAMP(1);
@@ -459,6 +509,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
       fft_mixed_row<T, L, MULTIWAVE>(exch, p.n_eff, p.mr_np, p.mr_radix, tw_src, t);
     } else if (!SSQ_ABL(2)) {
       if constexpr (PAIR) fft_pass_pair<T, LOGN, 0, false, false>(v[0], v[1], exch, twr, tw_src, t);
+      else if constexpr (C::SPLIT) fft_pass_split<T, LOGN, 0>(v[0], exch_s, twr, tw_it, t);
       else fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
     }
     // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
@@ -509,6 +560,8 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
         }
         zp[f][8] = v[f][8];
         frame_sync<MULTIWAVE>();
+      } else if constexpr (C::SPLIT && TXONLY) {
+        // (fetched bin by bin inside the epilogue: registers)
       } else if constexpr (!MULTIWAVE) {
         const int src = (lane - t) + ((L - t) & (L - 1));
 #pragma unroll
@@ -584,7 +637,22 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
 #pragma unroll
           for (int q = 0; q < 9; ++q) {
             const int k = t + L * q;
-            const cpx<T> zk = v[f][q], zn = zp[f][q];
+            cpx<T> zn;
+            if constexpr (C::SPLIT) {
+              // partner Z[N-k] right here, and the weight parked in the frame's (idle) exchange row until the column's
+              // scale is known: the lane reads back its own slots, so no ordering point is needed
+              const int src = (lane - t) + ((L - t) & (L - 1));
+              if (q < 8) {
+                zn.x = __shfl(v[f][15 - q].x, src);
+                zn.y = __shfl(v[f][15 - q].y, src);
+                if (t == 0) zn = (q == 0) ? v[f][0] : v[f][16 - q];
+              } else {
+                zn = v[f][8];
+              }
+            } else {
+              zn = zp[f][q];
+            }
+            const cpx<T> zk = v[f][q];
             const cpx<T> S = {zk.x + zn.x, zk.y - zn.y};
             const cpx<T> dS = {zk.y + zn.y, zn.x - zk.x};       // alpha * dSx
             int kk = k;
@@ -595,6 +663,14 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
             cpx<T> c = LEB ? cpx<T>{p.leb_unit, (T)0} : S;   // weight  (ssq_stft.rs:292-296)
             c.x = keep ? c.x : (T)0;
             c.y = keep ? c.y : (T)0;
+            if constexpr (C::SPLIT && !WKDBG) {
+              if (q < 8) {
+                exch_s[(2 * q) * 64 + t] = c.x;
+                exch_s[(2 * q + 1) * 64 + t] = c.y;
+              } else {
+                cv[8] = c;
+              }
+            } else
             cv[q] = c;
             dstb[q] = (keep ? kk : 0) * (PITCH * (int)sizeof(T)) + fl4;
             l1 += fabs(c.x) + fabs(c.y);
@@ -625,11 +701,15 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           }
         } else if constexpr (LEB) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
+          for (int q = 0; q < 8; ++q) {
+            if constexpr (C::SPLIT) cv[q].x = exch_s[(2 * q) * 64 + t];
+            atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
+          }
           if (t == 0) atomicAdd(reinterpret_cast<UT*>(pre + dstb[8]), (UT)to_fixed<T>(cv[8].x * scale));
         } else {
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
+            if constexpr (C::SPLIT) cv[q] = {exch_s[(2 * q) * 64 + t], exch_s[(2 * q + 1) * 64 + t]};
             atomicAdd(reinterpret_cast<UT*>(pre + dstb[q]), (UT)to_fixed<T>(cv[q].x * scale));
             atomicAdd(reinterpret_cast<UT*>(pim + dstb[q]), (UT)to_fixed<T>(cv[q].y * scale));
           }
@@ -692,7 +772,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN>::W * 64)) void stft_fused_kernel
           tr[j * RSTEP * PITCH] = 0;
           ti[j * RSTEP * PITCH] = 0;
           cpx<T> val;
-          if constexpr (TXONLY && !WKDBG) val = {(T)ire * sc, (T)iim * sc};
+          if constexpr (TXONLY && !WKDBG) val = {fixed_to_real<T>(ire) * sc, fixed_to_real<T>(iim) * sc};
           else val = {from_int<T>(ire), from_int<T>(iim)};
           if (store && (!ANYLEN || k0 + j * RSTEP < p.n_freqs)) og[j * gstep] = val;
         };

@@ -154,13 +154,14 @@ __device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, 
     kk = (u >= (T)last) ? last : (int)__builtin_ceilf(u);
     if (w != w) kk = 0;          // NaN never wins the scan: k stays 0
   } else {
-    const T tq = w / p.dw;
+    const T tq = w / p.dw;          // (w * inv_dw would do -- the tie window below re-decides exactly -- but measured 19 %
+                                    //  SLOWER in the fp64 fused kernel: profiles/r03_ab_f64_fixed.txt)
     const T u = tq - (T)0.5;
     kk = (u >= (T)last) ? last : (int)ceil(u);
-    if (w != w) {
-      kk = 0;
-    } else if (!skip) {
-      const T fr = fabs(tq - floor(tq) - (T)0.5);
+    if (w != w) kk = 0;
+    // ONE rarely taken branch around both exact re-decisions (the fused kernels inline this nine times per frame)
+    const T fr = fabs(tq - floor(tq) - (T)0.5);
+    if (!skip && w == w && (w > p.f_last || fr < (T)1e-7)) {
       if (w > p.f_last) {
         // fl(w - f_k) may tie for several k: the scan keeps the FIRST minimum.
         const T target = fabs(w - p.ssq_freqs[last]);
@@ -174,7 +175,7 @@ __device__ __forceinline__ bool phase_bin(const StftDev<T>& p, int i, cpx<T> S, 
           }
         }
         kk = lo;
-      } else if (fr < (T)1e-7) {
+      } else {
         // near a half-bin tie: decide with the reference's own distance expression
         int k0 = kk - 2 < 0 ? 0 : kk - 2;
         int k1 = kk + 2 > last ? last : kk + 2;

@@ -17,6 +17,7 @@ from ssqueeze_rs_amd import _lib  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--log2n", type=int, default=20)
+ap.add_argument("--n", type=int, default=0, help="signal length (default 2^log2n); scales stay 2^linspace(1, log2n - 1)")
 ap.add_argument("--na", type=int, default=256)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--steps", type=int, default=3)
@@ -25,7 +26,8 @@ ap.add_argument("--wavelet", default="morlet")
 ap.add_argument("--mode", default="ssq", help="ssq (ssq_cwt) | cwt (Wx and dWx out, L1 norm, unpadded) | cwt1 (Wx only)")
 a = ap.parse_args()
 lib = _lib.load()
-N, na, B = 1 << a.log2n, a.na, a.batch
+N, na, B = (a.n if a.n > 0 else 1 << a.log2n), a.na, a.batch
+n_label = f"2^{a.log2n}" if a.n <= 0 else str(N)
 code = _lib.SSQ_F32 if a.dtype == "f32" else _lib.SSQ_F64
 es = 4 if code == _lib.SSQ_F32 else 8
 scales = 2.0 ** np.linspace(1, a.log2n - 1, na)
@@ -74,7 +76,7 @@ tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
 if a.log2n == 20 and na == 256 and es == 4 and a.wavelet == "morlet" and os.path.exists(tf):
     with open(tf) as fh:
         traffic = json.load(fh)["total_GB_per_call"] * 1e9 * B
-print(json.dumps({"workload": f"{a.mode if a.mode != 'ssq' else 'ssq_cwt'} {a.wavelet} na={na} batch={B} x 2^{a.log2n} {a.dtype}", "ms": dt * 1e3,
+print(json.dumps({"workload": f"{a.mode if a.mode != 'ssq' else 'ssq_cwt'} {a.wavelet} na={na} batch={B} x {n_label} {a.dtype}", "ms": dt * 1e3,
                   "bins_per_s": bins / dt, "alg_GBps": alg / dt / 1e9, "frac_of_8TBps": alg / dt / 8e12,
                   "roofline_hbm": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": alg / dt / 8e12, "traffic": traffic,
