@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 HBM_MEASURED_COPY_GBS = 6290.0   # MI355X_MICROARCH.md: HBM3E 6.29 TB/s measured (float4 copy)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE_F64 = os.path.join("profiles", "r03_traffic_f64.json")      # the fp64 leg's own PMC passes (tools/pmc_f64.sh)
 
 
 def parse_args(argv=None):
@@ -123,12 +124,12 @@ def job_shape(world, rank, batch, total_batch):
 
 
 # ------------------------------------------------------------------------------------------------- pieces ----
-def measured_traffic(B, log2n, n_fft, hop):
+def measured_traffic(B, log2n, n_fft, hop, file=None):
     """HBM bytes per launch from the committed PMC run of this kernel (separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes, gfx950 correction applied; see profiles/README.md).  Counters cannot be read from inside
     the timed process, so this is a per-signal figure scaled to the batch; other shapes -> None."""
     try:
-        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+        with open(os.path.join(ROOT, file or TRAFFIC_FILE)) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["log2n"], w["n_fft"], w["hop"]) != (log2n, n_fft, hop):
@@ -568,7 +569,10 @@ def main():
         l64.upload(synth_rows(first, nd64, N, np.float64))
         v64 = l64.validate(first) if not args.no_validate else None
         _, k64 = l64.timed(max(3, args.steps // 2), 2)
-        r64 = roofline_of(l64, k64, None, "stft_fused_kernel<double,10,true,false,false> (+ edge-tile launch)")
+        r64 = roofline_of(l64, k64, measured_traffic(B, int(np.log2(N)), n_fft, hop, TRAFFIC_FILE_F64),
+                          "stft_fused_kernel<double,10,true,false,false> (8 waves; + edge-tile launch)")
+        if r64.get("traffic") is not None:
+            r64["traffic_source"] = TRAFFIC_FILE_F64
         sec["f64"] = {"dtype": "f64", "batch": B, "data": f"seeds {first}..{first + nd64 - 1} tiled to the batch",
                       "ms_per_step": float(np.mean(k64)),
                       "value": B * l64.bins / (float(np.mean(k64)) * 1e-3), "unit": "TF-bins/s",
