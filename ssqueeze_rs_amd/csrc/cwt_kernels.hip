@@ -31,6 +31,15 @@ namespace ssq {
 // LDS round trips of 8 waves (ablation: load 18, FFT 26, store 11, rest 11 us of a 62 us step-B launch).
 // Threads per tile block: 8 waves (one block per CU: the tile takes most of the LDS).  16 waves with twiddles read
 // from the table instead of registers measured 10 % slower on C4.
+#ifndef SSQ_CWT_F64_HALF
+#define SSQ_CWT_F64_HALF 1   // fp64 inverse step B on 2048 points: 4-wave blocks with 2-row tiles on HALF the LDS, so two blocks share a
+                             // CU and their load / FFT / store phases overlap (C4 fp64 16.85 -> 15.85 ms; for 4096 points the tile
+                             // would be ONE row = 16-byte segments, and step A loses its f1 table: C5 +10 %, profiles/r03_ab_c64half.txt)
+#endif
+template <typename T, int LOGM, int MODE>
+constexpr bool tile_half() {
+  return SSQ_CWT_F64_HALF && sizeof(T) == 8 && LOGM == 11 && MODE == 4 /* CWT_INV_B */;
+}
 template <typename T>
 constexpr int tile_threads() {
   return 512;
@@ -44,11 +53,13 @@ constexpr int pow2_floor(int v) {
 
 // NARROW (inverse step B in fp32): 8 transforms per tile instead of 16, so that two blocks share a CU and one's load /
 // store phases overlap the other's FFT (C4: -2 % against 16-row tiles; for step A and mode Z the 16-row tile wins).
-template <typename T, int LOGM, bool NARROW = false>
+template <typename T, int LOGM, bool NARROW = false, bool HALF_ = false>
 struct TileCfg {
   static constexpr int M = 1 << LOGM;
   static constexpr int L = M / 16;                                    // lanes per transform
-  static constexpr int THREADS = tile_threads<T>();
+  static constexpr bool HALF = HALF_;
+  static constexpr int THREADS = HALF ? 256 : 512;
+  static constexpr int LDS_BUDGET = (HALF ? 80 : 160) * 1024;
   static constexpr int TPR = (L >= THREADS) ? 1 : THREADS / L;   // transforms per round
   static constexpr int ROWP = M + M / 16 + 1;                         // odd-ish pitch: bank spread
   static constexpr int ROW_BYTES = ROWP * (int)sizeof(cpx<T>);
@@ -56,7 +67,7 @@ struct TileCfg {
 #define SSQ_CWT_CCAP32 16
 #endif
   static constexpr int CCAP = (sizeof(T) == 4) ? (NARROW ? 8 : SSQ_CWT_CCAP32) : 8;   // >= 128-B (64-B) global segments
-  static constexpr int CFIT = pow2_floor(160 * 1024 / ROW_BYTES);
+  static constexpr int CFIT = pow2_floor(LDS_BUDGET / ROW_BYTES);
   static constexpr int CWANT = (TPR > CCAP) ? TPR : CCAP;
   static constexpr int C = (CWANT < CFIT) ? CWANT : CFIT;             // transforms per tile
   static constexpr int LDS_BYTES = C * ROW_BYTES;
@@ -64,7 +75,7 @@ struct TileCfg {
   // W_P^(t0 k), k < M, of the tile's first column / residue t0, kept beside the tile when it fits: the W_P twiddle
   // of element (c, k) is then f1[k] * tw_f2[c, k] -- one LDS read and one COALESCED table load instead of two
   // 64-address gathers from the split W_P table (which made step A's store phase TA-bound)
-  static constexpr bool F1 = (LDS_BYTES + M * (int)sizeof(cpx<T>) <= 160 * 1024);
+  static constexpr bool F1 = (LDS_BYTES + M * (int)sizeof(cpx<T>) <= LDS_BUDGET);
   static constexpr int LDS_TOTAL = LDS_BYTES + (F1 ? M * (int)sizeof(cpx<T>) : 0);
   static_assert(LOGM >= 4 && LOGM <= 12, "tile FFT length");
   static_assert(C >= TPR && C % TPR == 0, "whole rounds");
@@ -133,16 +144,17 @@ constexpr bool tile_narrow() {
 // tiles and the single-pass scales up to Q = 512 (fp32); their load / FFT / store phases then overlap across blocks.
 template <typename T, int LOGM, int MODE>
 constexpr int tile_blocks_per_cu() {
-  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>(), tile_half<T, LOGM, MODE>()>;
+  if (tile_half<T, LOGM, MODE>()) return 2;
   return (sizeof(T) == 4 && (MODE == CWT_INV_B || MODE == CWT_INV_Z) && K::LDS_TOTAL <= 80 * 1024 && K::C == K::TPR) ? 2 : 1;
 }
 
 // One tile = C transforms of length M in LDS.  MODE is a compile-time CwtMode: every phase is straight-line code
 // over batches of U elements per thread, so U global loads (or stores) are in flight per thread instead of one.
 template <typename T, int LOGM, int MODE>
-__global__ __launch_bounds__((tile_threads<T>()), (tile_blocks_per_cu<T, LOGM, MODE>()))
+__global__ __launch_bounds__((TileCfg<T, LOGM, tile_narrow<T, MODE>(), tile_half<T, LOGM, MODE>()>::THREADS), (tile_blocks_per_cu<T, LOGM, MODE>()))
 void cwt_tile_kernel(CwtDev<T> p) {
-  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>(), tile_half<T, LOGM, MODE>()>;
   constexpr int M = K::M, L = K::L, C = K::C, ROWP = K::ROWP;
   constexpr int kTileThreads = K::THREADS;
   // twiddles in registers pay only when a thread runs several rounds with them
@@ -329,7 +341,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
 
 template <typename T, int LOGM, int MODE>
 static hipError_t launch_tile_mode(const CwtDev<T>& p, hipStream_t stream) {
-  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>()>;
+  using K = TileCfg<T, LOGM, tile_narrow<T, MODE>(), tile_half<T, LOGM, MODE>()>;
   dim3 grid;
   if (MODE == CWT_FWD_A || MODE == CWT_INV_A) {
     grid = dim3((unsigned)(((1LL << p.log_p2) + K::C - 1) / K::C), (unsigned)p.n_transforms, 1);
