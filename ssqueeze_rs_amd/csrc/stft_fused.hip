@@ -259,6 +259,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
   bool have_prev = false;
   long long psig = 0;
   int pframe0 = 0;
+  const int grid_n = (int)gridDim.x;          // (read once: inside the loop it is a scalar load + wait per tile)
 #pragma unroll 1
   while (true) {
     const int frame0 = tile_frame0(jt);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
     if (asym_early && have_prev) read_out(psig, pframe0);
     // next tile of this block; prefetch its samples behind this frame's FFT
     long long nsig = sig;
-    int njt = jt + (int)gridDim.x;
+    int njt = jt + grid_n;
     while (njt >= p.tiles_per_signal) {
       njt -= p.tiles_per_signal;
       ++nsig;

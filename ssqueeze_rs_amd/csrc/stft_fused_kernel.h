@@ -417,13 +417,14 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN, MODE != 0>::W * 64)) void stft_f
     int ok;
   };
   const long long n_sig = p.total_tiles / p.tiles_per_signal;
+  const int grid_n = (int)gridDim.x;          // (read once: inside the loop it is a scalar load + wait per iteration)
   auto advance = [&](const Item& c) {
     Item n = c;
     n.ig = c.ig + 1;
     if (n.ig == NG) {
       n.ig = 0;
       long long ns = c.tl.sig;
-      int nft = c.tl.ft + (int)gridDim.x;
+      int nft = c.tl.ft + grid_n;
       while (nft >= p.tiles_per_signal) {
         nft -= p.tiles_per_signal;
         ++ns;
