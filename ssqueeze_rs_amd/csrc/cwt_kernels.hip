@@ -168,7 +168,11 @@ void cwt_tile_kernel(CwtDev<T> p) {
 #ifndef SSQ_CWT_U
 #define SSQ_CWT_U 8
 #endif
-  constexpr int U = PER < SSQ_CWT_U ? PER : SSQ_CWT_U;  // batch
+#ifndef SSQ_CWT_U64
+#define SSQ_CWT_U64 8
+#endif
+  constexpr int UCAP = sizeof(T) == 8 ? SSQ_CWT_U64 : SSQ_CWT_U;
+  constexpr int U = PER < UCAP ? PER : UCAP;            // batch
   static_assert(PER % U == 0, "whole batches");
   constexpr bool USE_F1 = K::F1 && (MODE == CWT_FWD_A || MODE == CWT_INV_A || MODE == CWT_INV_Z);
   __shared__ __attribute__((aligned(16))) unsigned char smem[USE_F1 ? K::LDS_TOTAL : K::LDS_BYTES];
@@ -257,7 +261,7 @@ void cwt_tile_kernel(CwtDev<T> p) {
 
   // ---------------- length-M forward FFTs in LDS ----------------
   {
-    const int slot = tid / L;
+    const int slot = (L >= 64) ? __builtin_amdgcn_readfirstlane(tid / L) : tid / L;   // (a wave-uniform row index stays scalar)
     const int t = tid % L;
     cpx<T> twr[3][16];
     if constexpr (TW_REGS) {
@@ -579,7 +583,7 @@ __global__ __launch_bounds__((tile_threads<T>())) void cwt_tile_ssq_kernel(CwtDe
   }
   __syncthreads();
   {
-    const int slot = tid / L;
+    const int slot = (L >= 64) ? __builtin_amdgcn_readfirstlane(tid / L) : tid / L;   // (a wave-uniform row index stays scalar)
     const int t = tid % L;
     cpx<T> twr[3][16];
     if constexpr (TW_REGS) {

@@ -108,7 +108,16 @@ __global__ __launch_bounds__(WAVES * 64, 16 / WAVES) void stft_tx1024_kernel(Stf
 
   const int tid = threadIdx.x;
   const int t = tid & 63;          // lane = position inside the frame
+#ifndef SSQ_FL_SCALAR
+#define SSQ_FL_SCALAR 1
+#endif
+#if SSQ_FL_SCALAR
+  // wave-uniform by construction: say so, and everything derived from it (exchange row, column-scale slot, frame index)
+  // lives in scalar registers instead of (spilled) vector ones
+  const int fl = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave = frame inside the tile
+#else
   const int fl = tid >> 6;         // wave = frame inside the tile
+#endif
   cpx<T>* exch = exch_all + fl * H::EXH_ELEMS;
   auto xphys = [](int i) { return i + H::EXH_PAD * (i >> 4); };
 

@@ -365,7 +365,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN, MODE != 0>::W * 64)) void stft_f
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: keeps its derived values in scalar registers
   int slot, t;
   if constexpr (L <= 64) {
     slot = wave * C::FPW + lane / L;
