@@ -124,6 +124,9 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
 
   // W_F^(c j), j < R, for the columns c = tid + THREADS * u this thread transforms (forward sign): 1, w, w^2 ...
   constexpr int CPT = 1024 / THREADS;                          // columns per thread in the length-R transforms: 1 or 2
+#ifndef SSQ_OS_WJ_KEEP
+#define SSQ_OS_WJ_KEEP 0     // 1: the R powers live in registers across all scales (2 R CPT of the 128 the kernel may use)
+#endif
   cpx<float> wj[CPT][R];
 #pragma unroll
   for (int u = 0; u < CPT; ++u) {
@@ -211,6 +214,23 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
   for (int s = p.s_begin; s < p.s_end; ++s) {
     // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < R / 2; on conjugated data (ifft = conj fft
     //          conj); length-R transform over r (R / 2 live inputs), twiddle W_F^(c j), rows j of both kinds
+#if !SSQ_OS_WJ_KEEP
+    {
+      // the twiddle powers are rebuilt per scale (one cached table read and R - 2 products per column) instead of
+      // living in 2 R CPT registers through the wave transform and the epilogue, where the kernel spills: the opaque
+      // zero offset keeps the (loop-invariant) rebuild inside the loop.  C4 3.44 -> 3.25 ms (profiles/r03_ab_os_wj.txt)
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      const cpx<float>* twp = p.tw1024 + z;
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        wj[u][0] = {1.0f, 0.0f};
+        wj[u][1] = os_wF<R>(twp, tid + THREADS * u);
+#pragma unroll
+        for (int j = 2; j < R; ++j) wj[u][j] = cmul(wj[u][j - 1], wj[u][1]);
+      }
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
       const int c = tid + THREADS * u;
