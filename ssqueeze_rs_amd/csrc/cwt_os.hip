@@ -15,6 +15,7 @@
 // Two geometries (template R = rows of 1024 points): R = 8 as above (16 waves, one block per CU), and R = 4 -- 4096-point
 // transforms, 2048 output samples, a 1024-sample halo, 8 waves, TWO blocks per CU whose phases overlap -- for the scales
 // whose wavelet fits the shorter halo.
+#include <type_traits>
 #include "cwt_bin.h"
 #include "cwt_kernels.h"
 #include "fft_wave1024.h"
@@ -171,17 +172,10 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
   // ---- all eligible scales, ascending ----
   const int kind_w = wv >= R ? 1 : 0;                          // waves 0 .. R-1: Wx rows, R .. 2R-1: dWx rows
   cpx<float>* myrow = zb[kind_w] + (wv & (R - 1)) * PT;
-  int k_cur[4] = {-1, -1, -1, -1};
-  cpx<float> acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
   CwtSsqDev<float> q = p.q;
   cpx<float>* __restrict__ Tx = q.Tx;
   // (no-return float atomics instead of the read-modify-write of a finished run: 0.75 ms SLOWER on C4,
   // profiles/r02_ab_cwt_os.txt -- 1.3e8 L2 atomics cost more than the loads they replace)
-  auto flush = [&](int i, long long col) {
-    cpx<float>* d = Tx + (long long)k_cur[i] * q.N + col;
-    const cpx<float> tv = *d;
-    *d = {tv.x + acc[i].x, tv.y + acc[i].y};
-  };
   // this thread's spectrum values stay in registers for all scales; the wavelet row of the NEXT scale is requested
   // behind the transform of the current one
   cpx<float> xk[CPT][H2];
@@ -210,10 +204,23 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
       }
       hk[u][r] = p.H[k];
     }
+  int k_cur[4] = {-1, -1, -1, -1};                              // (declared behind the spectrum set-up: its double-precision
+  cpx<float> acc[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};   //  sincospi is the kernel's register peak)
+  auto flush = [&](int i, long long col) {
+    cpx<float>* d = Tx + (long long)k_cur[i] * q.N + col;
+    const cpx<float> tv = *d;
+    *d = {tv.x + acc[i].x, tv.y + acc[i].y};
+  };
 #pragma unroll 1
   for (int s = p.s_begin; s < p.s_end; ++s) {
     // phase 1: Y[k] = X_b[k] H_s[k] (* i xi_k / dt), k = 1024 r + c, r < R / 2; on conjugated data (ifft = conj fft
     //          conj); length-R transform over r (R / 2 live inputs), twiddle W_F^(c j), rows j of both kinds
+    const cpx<float>* xs_it = xs;
+    if constexpr (CPLX) {
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      xs_it += z;
+    }
 #if !SSQ_OS_WJ_KEEP
     {
       // the twiddle powers are rebuilt per scale (one cached table read and R - 2 products per column) instead of
@@ -238,7 +245,9 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
 #pragma unroll
       for (int r = 0; r < H2; ++r) {
         const int k = 1024 * r + c;
-        const cpx<float> x = xk[u][r];
+        // (analytic-input tiles keep all R rows of the spectrum: re-read per scale from the tile's workspace -- cache
+        //  resident -- instead of holding 2 R CPT more registers than the kernel has)
+        const cpx<float> x = CPLX ? xs_it[k] : xk[u][r];
         const float h = hk[u][r];
         const cpx<float> y = {x.x * h, -x.y * h};                // conj(X H)
         a[r] = y;
@@ -284,10 +293,22 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
     // for the four columns instead of one per column)
     cpx<float>* fl_ptr[4];
     cpx<float> fl_val[4];
+    // The strided columns of the decimated / full-circle tiles are loop invariant, and hoisted out of the scale loop they
+    // and the addresses built on them (Tx, the test hooks) hold ~30 registers -- which pushed the run state into scratch.
+    // An opaque zero per scale keeps the (two-instruction) column arithmetic here.
+    int ph = phase;
+    if constexpr (LOGM != 0) {
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      ph += z;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int nl = HALO + tid + THREADS * i;                   // position inside the F-sample frame
-      const long long col = n0 + ((long long)(tid + THREADS * i) << logm) + phase;
+      // (decimated / full-circle tiles: 32-bit column arithmetic -- tiled plans have N < 2^24 -- the kernel runs at its
+      //  128-register cap and four 64-bit strided columns pushed the run state into scratch)
+      using col_t = std::conditional_t<LOGM == 0, long long, int>;
+      const col_t col = (col_t)n0 + ((col_t)(tid + THREADS * i) << logm) + (col_t)ph;
       const cpx<float> Wv = zb[0][(nl & (R - 1)) * PT + (nl >> LOGR)];
       const cpx<float> dW = zb[1][(nl & (R - 1)) * PT + (nl >> LOGR)];
       fl_ptr[i] = nullptr;
