@@ -346,7 +346,7 @@ __global__ __launch_bounds__(OsCfg<R>::THREADS, SSQ_OS_WAVES_PER_SIMD) void cwt_
       for (int i = 0; i < 4; ++i)
         if (fl_ptr[i]) *fl_ptr[i] = {tv[i].x + fl_val[i].x, tv[i].y + fl_val[i].y};
     }
-    __syncthreads();
+    __syncthreads();       // (an LDS-only barrier here and behind phases 1 / 2 -- no vector-memory drain -- measured +-0: 3.00 ms)
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
