@@ -97,6 +97,11 @@ int ssq_rccl_unique_id(void* id128) {
   if (!id128) SSQ_FAIL("id128 is NULL");
   Rccl* r = nullptr;
   if (int rc = need_rccl(&r)) return rc;
+  {
+    // (RCCL itself aborts its bootstrap with a "[FATAL ERROR]" line on stderr when no device is visible: say it ourselves)
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) SSQ_FAIL("no ROCm device is visible: RCCL needs one");
+  }
   NcclUniqueId id;
   SSQ_NCCL(r, r->GetUniqueId(&id));
   std::memcpy(id128, id.internal, sizeof(id.internal));
