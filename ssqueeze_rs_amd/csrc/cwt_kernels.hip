@@ -98,7 +98,10 @@ __device__ __forceinline__ cpx<T> load_spectrum(const CwtDev<T>& p, int tr, long
   const long long bs = p.band[s];                       // psih_s is exactly zero from here on: not stored
   T psi = p.psih[p.psi_off[s] + (nn < bs ? nn : bs - 1)];
   const cpx<T> xv = p.xh[nn];
-  if (n > half || nn >= bs) psi = (T)0;                 // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536)
+  // analytic wavelets: w < 0 -> 0 (cwt.rs:512,:536).  As a FACTOR, not a select: with `psi = cond ? 0 : psi` the compiler
+  // sinks the table load behind the condition -- a branch per element, and every element of a batch then waits for its
+  // own loads (the step-A load phase ran its 16 elements per thread as 16 serial memory round trips)
+  psi *= (n > half || nn >= bs) ? (T)0 : (T)1;
   cpx<T> v = {xv.x * psi, xv.y * psi};                  // cwt.rs:238-240
   if (kind == 1) {                                      // * Complex(0, xi/dt)  cwt.rs:205-208
     const T xi = (T)n * p.xi_step;
