@@ -154,8 +154,33 @@ int upload_tw(void** dst, long long n, long long P_total, long long stride) {
 template <typename T>
 int build_tables(ssq_cwt_plan* pl) {
   const long long P1 = 1LL << pl->log_p1, P2 = 1LL << pl->log_p2;
-  if (int rc = upload_tw<T>(&pl->d_tw1, P1, P1, 1)) return rc;
-  if (int rc = upload_tw<T>(&pl->d_tw2, P2, P2, 1)) return rc;
+  // W_M table, and behind it (fp64 plans) the per-pass compact tables [m][k] = exp(-2 pi i k m / (NS R)) of the tile transform
+  auto upload_tw_tile = [&](void** dst, int logm) -> int {
+    const long long M = 1LL << logm;
+    const long long extra = (sizeof(T) == 8 && logm >= 4 && logm <= 12) ? cwt_tw_compact_elems(logm) : 0;
+    std::vector<cpx<T>> h((size_t)(M + extra));
+    for (long long i = 0; i < M; ++i) {
+      const long double ang = 2.0L * kPI * (long double)i / (long double)M;
+      h[(size_t)i] = {(T)cosl(ang), (T)(-sinl(ang))};
+    }
+    if (extra > 0) {
+      long long off = M;
+      for (int P = 1; P < num_passes(logm); ++P) {
+        const int R = pass_radix(logm, P), NS = pass_ns(logm, P);
+        for (int m = 0; m < R; ++m)
+          for (int k = 0; k < NS; ++k) {
+            const long double ang = 2.0L * kPI * (long double)((long long)k * m) / (long double)((long long)NS * R);
+            h[(size_t)(off + (long long)m * NS + k)] = {(T)cosl(ang), (T)(-sinl(ang))};
+          }
+        off += (long long)R * NS;
+      }
+    }
+    SSQ_HIP(hipMalloc(dst, sizeof(cpx<T>) * h.size()));
+    SSQ_HIP(hipMemcpy(*dst, h.data(), sizeof(cpx<T>) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+  };
+  if (int rc = upload_tw_tile(&pl->d_tw1, pl->log_p1)) return rc;
+  if (int rc = upload_tw_tile(&pl->d_tw2, pl->log_p2)) return rc;
   if (pl->two_step) {
     // in-tile factors of the W_P twiddle (the other factor, W_P^(t0 k), is formed per tile in LDS)
     auto upload_f2 = [&](void** dst, long long rows, long long cols, bool row_is_k) -> int {
@@ -339,6 +364,7 @@ CwtDev<T> base_dev(const ssq_cwt_plan* pl, char* ws) {
   p.ybuf = (cpx<T>*)(ws + L.ybuf);
   p.psih = (const T*)pl->d_psih;
   p.psi_off = pl->d_psi_off;
+  p.tw_compact = sizeof(T) == 8 ? 1 : 0;      // d_tw1 / d_tw2 of fp64 plans carry the per-pass compact tables (build_tables)
   p.tw_hi = (const cpx<T>*)pl->d_twhi;
   p.tw_lo = (const cpx<T>*)pl->d_twlo;
   p.band = pl->d_band;
@@ -470,6 +496,7 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
       z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
+      z.tw_compact = 0;                                          // (the single-pass tables carry no compact part)
       z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
       const int step = group > 0 ? group : s1 - s0;
       for (int c0 = s0; c0 < s1; c0 += step) {
@@ -535,6 +562,7 @@ int run_inverse_ssq(const ssq_cwt_plan* pl, CwtDev<T> p, const CwtSsqDev<T>& q, 
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
       z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
+      z.tw_compact = 0;                                          // (the single-pass tables carry no compact part)
       z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
       SSQ_HIP(launch_cwt_tile_ssq<T>(CWT_INV_Z, z, q, st));
     } else {

@@ -24,6 +24,8 @@ struct CwtDev {
   const T* psih;         // wavelet table, scale s at psi_off[s], band[s] entries (zero beyond)   (cwt.rs:492-547)
   const long long* psi_off;
   const cpx<T>* tw_m;    // W_M^i for the transform length of this launch
+  int tw_compact;        // 1: behind the M entries of tw_m lie the passes' own tables [m][k] (cwt_tw_compact_elems): lanes read
+                         //    consecutive entries instead of gathering k*m*stride (fp64 tiles: no twiddles in registers)
   const cpx<T>* tw_hi;   // W_P^(i << 12)
   const cpx<T>* tw_lo;   // W_P^i, i < 4096
   const cpx<T>* tw_f2;   // in-tile factor of the W_P twiddle: step A [M][C]: W_P^(c k1); mode Z [C][M]: W_P^(c k)
@@ -47,6 +49,12 @@ struct CwtDev {
   T xi_step;             // (2*pi/P)/dt : xi_k/dt = k * xi_step      (wavelets/base.rs:18-33, cwt.rs:207)
 };
 
+// elements of the per-pass compact twiddle tables of a length-2^logm tile transform (passes 1 .. last: R * NS each)
+inline long long cwt_tw_compact_elems(int logm) {
+  long long n = 0;
+  for (int P = 1; P < num_passes(logm); ++P) n += (long long)pass_radix(logm, P) * pass_ns(logm, P);
+  return n;
+}
 template <typename T>
 hipError_t launch_cwt_tile(int mode, const CwtDev<T>& p, hipStream_t stream);
 // transforms per tile (C) of the length-2^logm tile kernel: the host sizes the tw_f2 tables with it

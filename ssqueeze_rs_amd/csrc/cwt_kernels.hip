@@ -290,7 +290,8 @@ void cwt_tile_kernel(CwtDev<T> p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = row[exch_phys(t + L * q)];
       frame_sync<K::MULTIWAVE>();
-      fft_pass<T, LOGM, 0, false, TW_REGS, K::MULTIWAVE>(v, row, twr, p.tw_m, t);
+      if (sizeof(T) == 8 && p.tw_compact) fft_pass_compact<T, LOGM, 0, K::MULTIWAVE>(v, row, p.tw_m + M, t);
+      else fft_pass<T, LOGM, 0, false, TW_REGS, K::MULTIWAVE>(v, row, twr, p.tw_m, t);
 #pragma unroll
       for (int q = 0; q < 16; ++q) row[exch_phys(t + L * q)] = v[q];
     }

@@ -91,6 +91,20 @@ __device__ __forceinline__ void fft_pass(cpx<T> (&v)[16], cpx<T>* exch, const cp
   }
 }
 
+// The transform with every pass's twiddles read from that pass's own table [m][k] (R * NS entries, k fastest): the lanes
+// of a load touch consecutive entries instead of gathering k * m * stride from the W_N table.  `tw_c` = the tables of
+// passes 1, 2, ... back to back.
+template <typename T, int LOGN, int P, bool MULTIWAVE>
+__device__ __forceinline__ void fft_pass_compact(cpx<T> (&v)[16], cpx<T>* exch, const cpx<T>* __restrict__ tw_c, int t) {
+  const cpx<T> unused[3][16] = {};
+  fft_compute<T, LOGN, P, false, false, true>(v, unused, tw_c, t);
+  if constexpr (P < num_passes(LOGN) - 1) {
+    fft_exchange<T, LOGN, P, MULTIWAVE>(v, exch, t);
+    constexpr int ADV = (P == 0) ? 0 : pass_radix(LOGN, P) * pass_ns(LOGN, P);
+    fft_pass_compact<T, LOGN, P + 1, MULTIWAVE>(v, exch, tw_c + ADV, t);
+  }
+}
+
 // The same transform for a frame inside ONE wave with an exchange row of T instead of cpx<T>: the real parts go through
 // the row, then the imaginary parts (fp64: twice the DS instructions of half the width -- the same bytes -- for half the
 // LDS footprint, which is what lets eight fp64 frames share a CU).
