@@ -36,7 +36,8 @@ struct ssq_cwt_plan {
   long long* d_psi_off = nullptr;
   void* d_tw1 = nullptr;       // W_{P1}^i
   void* d_tw2 = nullptr;       // W_{P2}^i
-  void* d_twz = nullptr;       // W_Q^i at [Q, 2Q) for Q = 16 .. 2048 (mode Z)
+  void* d_twz = nullptr;       // W_Q^i for Q = 16 .. 2048 (mode Z) at twz_off[log2 Q] (fp64: + the compact per-pass tables)
+  long long twz_off[16] = {0};
   void* d_f2a = nullptr;       // step A: [P1][C] W_P^(c k1)
   void* d_f2z[13] = {};        // mode Z, per log2 Q: [C][Q] W_P^(c k)
   std::vector<int> zoom_logq;  // per scale: log2 Q of the band-limited single-pass path, 0 = two-step path
@@ -202,12 +203,26 @@ int build_tables(ssq_cwt_plan* pl) {
       if (!used) continue;
       if (int rc = upload_f2(&pl->d_f2z[lq], cwt_tile_rows<T>(lq), 1LL << lq, false)) return rc;
     }
-    std::vector<cpx<T>> hz(2 * kZoomTabQ);
-    for (long long Q = 16; Q <= kZoomTabQ; Q *= 2)
+    // W_Q for Q = 16 .. kZoomTabQ, each followed (fp64 plans) by its per-pass compact tables; pl->twz_off[log2 Q] says where
+    std::vector<cpx<T>> hz;
+    for (int lq = 4; (1LL << lq) <= kZoomTabQ; ++lq) {
+      const long long Q = 1LL << lq;
+      pl->twz_off[lq] = (long long)hz.size();
       for (long long i = 0; i < Q; ++i) {
         const long double ang = 2.0L * kPI * (long double)i / (long double)Q;
-        hz[(size_t)(Q + i)] = {(T)cosl(ang), (T)(-sinl(ang))};
+        hz.push_back({(T)cosl(ang), (T)(-sinl(ang))});
       }
+      if (sizeof(T) == 8) {
+        for (int P = 1; P < num_passes(lq); ++P) {
+          const int R = pass_radix(lq, P), NS = pass_ns(lq, P);
+          for (int m = 0; m < R; ++m)
+            for (int k = 0; k < NS; ++k) {
+              const long double ang = 2.0L * kPI * (long double)((long long)k * m) / (long double)((long long)NS * R);
+              hz.push_back({(T)cosl(ang), (T)(-sinl(ang))});
+            }
+        }
+      }
+    }
     SSQ_HIP(hipMalloc(&pl->d_twz, sizeof(cpx<T>) * hz.size()));
     SSQ_HIP(hipMemcpy(pl->d_twz, hz.data(), sizeof(cpx<T>) * hz.size(), hipMemcpyHostToDevice));
   }
@@ -495,8 +510,8 @@ int run_inverse(const ssq_cwt_plan* pl, CwtDev<T> p, cpx<T>* Wx, cpx<T>* dWx, bo
       CwtDev<T> z = p;
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
-      z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
-      z.tw_compact = 0;                                          // (the single-pass tables carry no compact part)
+      z.tw_m = (const cpx<T>*)pl->d_twz + pl->twz_off[lq];
+      z.tw_compact = sizeof(T) == 8 ? 1 : 0;
       z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
       const int step = group > 0 ? group : s1 - s0;
       for (int c0 = s0; c0 < s1; c0 += step) {
@@ -561,8 +576,8 @@ int run_inverse_ssq(const ssq_cwt_plan* pl, CwtDev<T> p, const CwtSsqDev<T>& q, 
       z.n_transforms = (s1 - s0) * 2;
       z.log_p2 = lq;
       z.log_p1 = pl->logP - lq;
-      z.tw_m = (const cpx<T>*)pl->d_twz + (1LL << lq);
-      z.tw_compact = 0;                                          // (the single-pass tables carry no compact part)
+      z.tw_m = (const cpx<T>*)pl->d_twz + pl->twz_off[lq];
+      z.tw_compact = sizeof(T) == 8 ? 1 : 0;
       z.tw_f2 = (const cpx<T>*)pl->d_f2z[lq];
       SSQ_HIP(launch_cwt_tile_ssq<T>(CWT_INV_Z, z, q, st));
     } else {
