@@ -95,7 +95,14 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
   const int n = pl->n_fft;
   const long double PI = 3.14159265358979323846264338327950288L;
   const int m = pl->fft_len > 0 ? pl->fft_len : n;             // fused kernel's transform length
-  std::vector<cpx<T>> tw((size_t)m), win2((size_t)m, cpx<T>{(T)0, (T)0});
+  // (fp64 plans of the power-of-two kernel: behind the W_m table the passes' compact tables [mm][k] = exp(-2 pi i k mm / (NS R)),
+  //  read coalesced by the 8-wave n_fft = 1024 kernel -- FusedCfg::SPLIT -- instead of gathered from W_m)
+  long long tw_extra = 0;
+  int logm = 0;
+  while ((1 << logm) < m) ++logm;
+  if (sizeof(T) == 8 && (1 << logm) == m && !pl->blue && pl->mr_np == 0)
+    for (int P = 1; P < num_passes(logm); ++P) tw_extra += (long long)pass_radix(logm, P) * pass_ns(logm, P);
+  std::vector<cpx<T>> tw((size_t)(m + tw_extra)), win2((size_t)m, cpx<T>{(T)0, (T)0});
   std::vector<double> twre((size_t)n), twim((size_t)n);
   for (int i = 0; i < n; ++i) {
     const long double ang = 2.0L * PI * (long double)i / (long double)n;
@@ -106,6 +113,18 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
   for (int i = 0; i < m; ++i) {
     const long double ang = 2.0L * PI * (long double)(i % tw_n) / (long double)tw_n;
     tw[i] = {(T)cosl(ang), (T)(-sinl(ang))};
+  }
+  if (tw_extra > 0) {
+    long long off = m;
+    for (int P = 1; P < num_passes(logm); ++P) {
+      const int R = pass_radix(logm, P), NS = pass_ns(logm, P);
+      for (int mm = 0; mm < R; ++mm)
+        for (int k = 0; k < NS; ++k) {
+          const long double ang = 2.0L * PI * (long double)((long long)k * mm) / (long double)((long long)NS * R);
+          tw[(size_t)(off + (long long)mm * NS + k)] = {(T)cosl(ang), (T)(-sinl(ang))};
+        }
+      off += (long long)R * NS;
+    }
   }
   std::vector<host::cd> chirp((size_t)n);                      // exp(-i*pi*j^2/n), j^2 reduced mod 2n
   if (pl->blue) {
@@ -134,10 +153,10 @@ int upload_tables(ssq_stft_plan* pl, const std::vector<double>& g, const std::ve
   }
   std::vector<T> fr((size_t)pl->n_freqs);
   for (int i = 0; i < pl->n_freqs; ++i) fr[i] = (T)pl->ssq_freqs[i];
-  SSQ_HIP(hipMalloc(&pl->d_tw, sizeof(cpx<T>) * m));
+  SSQ_HIP(hipMalloc(&pl->d_tw, sizeof(cpx<T>) * tw.size()));
   SSQ_HIP(hipMalloc(&pl->d_win2, sizeof(cpx<T>) * m));
   SSQ_HIP(hipMalloc(&pl->d_ssq_freqs, sizeof(T) * pl->n_freqs));
-  SSQ_HIP(hipMemcpy(pl->d_tw, tw.data(), sizeof(cpx<T>) * m, hipMemcpyHostToDevice));
+  SSQ_HIP(hipMemcpy(pl->d_tw, tw.data(), sizeof(cpx<T>) * tw.size(), hipMemcpyHostToDevice));
   SSQ_HIP(hipMemcpy(pl->d_win2, win2.data(), sizeof(cpx<T>) * m, hipMemcpyHostToDevice));
   SSQ_HIP(hipMemcpy(pl->d_ssq_freqs, fr.data(), sizeof(T) * pl->n_freqs, hipMemcpyHostToDevice));
   SSQ_HIP(hipMalloc((void**)&pl->d_g, sizeof(double) * n));

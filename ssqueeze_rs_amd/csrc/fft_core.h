@@ -140,13 +140,15 @@ __device__ __forceinline__ void fft_exchange_split(cpx<T> (&v)[16], T* exch, int
   frame_sync<false>();
 }
 
+// `tw_c`: the passes' compact tables [m][k] back to back (see fft_pass_compact): coalesced reads instead of gathers
 template <typename T, int LOGN, int P>
 __device__ __forceinline__ void fft_pass_split(cpx<T> (&v)[16], T* exch, const cpx<T> (&twr)[3][16],
-                                               const cpx<T>* __restrict__ tw_tab, int t) {
-  fft_compute<T, LOGN, P, false, false>(v, twr, tw_tab, t);
+                                               const cpx<T>* __restrict__ tw_c, int t) {
+  fft_compute<T, LOGN, P, false, false, true>(v, twr, tw_c, t);
   if constexpr (P < num_passes(LOGN) - 1) {
     fft_exchange_split<T, LOGN, P>(v, exch, t);
-    fft_pass_split<T, LOGN, P + 1>(v, exch, twr, tw_tab, t);
+    constexpr int ADV = (P == 0) ? 0 : pass_radix(LOGN, P) * pass_ns(LOGN, P);
+    fft_pass_split<T, LOGN, P + 1>(v, exch, twr, tw_c + ADV, t);
   }
 }
 

@@ -510,7 +510,7 @@ __global__ __launch_bounds__((FusedCfg<T, LOGN, MODE != 0>::W * 64)) void stft_f
       fft_mixed_row<T, L, MULTIWAVE>(exch, p.n_eff, p.mr_np, p.mr_radix, tw_src, t);
     } else if (!SSQ_ABL(2)) {
       if constexpr (PAIR) fft_pass_pair<T, LOGN, 0, false, false>(v[0], v[1], exch, twr, tw_src, t);
-      else if constexpr (C::SPLIT) fft_pass_split<T, LOGN, 0>(v[0], exch_s, twr, tw_it, t);
+      else if constexpr (C::SPLIT) fft_pass_split<T, LOGN, 0>(v[0], exch_s, twr, tw_it + N, t);   // compact tables behind W_N
       else fft_pass<T, LOGN, 0, false, TW_REGS, MULTIWAVE>(v[0], exch, twr, tw_src, t);
     }
     // lane t now holds Z[t + L*q], q = 0..15 (natural order residue class t mod L)
